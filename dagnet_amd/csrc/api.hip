@@ -1,0 +1,771 @@
+// Host side of libdagnet_hip.so: weight re-packing into MFMA fragment order, scene->tile planning,
+// LDS layout, argument checks and the extern "C" entry points declared in include/dagnet_hip.h.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dagnet_hip.h"
+#include "params.h"
+
+extern "C" hipError_t dn_launch_rollout(int mode, const void *d_static, const DnRun *run, size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t dn_launch_adjacency(int type, float sigma, int top_k, const int32_t *scene_ptr, const int32_t *row_scene,
+                                          const int64_t *blk_off, int N, int T, const float *pos, float *out, int64_t ld,
+                                          int64_t tstride, hipStream_t st);
+extern "C" hipError_t dn_launch_best_of_k(const int32_t *scene_ptr, int S, int N, int K, int T, const float *rel,
+                                          const float *start, const float *gt, float *ade, float *fde, float *scene_best,
+                                          double *sums, hipStream_t st);
+extern "C" hipError_t dn_launch_loss_finalize(int n_tiles, int N, const double *part, double *losses, hipStream_t st);
+extern "C" hipError_t dn_launch_abs_errors(int T, int N, const float *pred, const float *gt, float *ade, float *fde, hipStream_t st);
+extern "C" hipError_t dn_launch_scene_min_sum(const int32_t *scene_ptr, int S, int N, int K, const float *ade, const float *fde,
+                                              float *scene_best, double *sums, hipStream_t st);
+extern "C" hipError_t dn_launch_rel_to_abs(int T, int N, const float *rel, const float *start, float *out, hipStream_t st);
+extern "C" hipError_t dn_launch_categorical(int N, int G, const float *w, const float *q, uint64_t seed, int32_t *out, hipStream_t st);
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIP_TRY(x)                                                                                   \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) return fail(DAGNET_ERR_HIP, "%s: %s", #x, hipGetErrorString(e_));      \
+    } while (0)
+
+static inline int pad8(int x) { return (x + 7) & ~7; }
+static inline int pad32(int x) { return (x + 31) & ~31; }
+
+struct dagnet_model {
+    dagnet_config cfg;
+    DnDims dims;
+    DnWeights w;
+    float *d_wp = nullptr;
+    size_t wp_floats = 0;
+    int device = 0;
+};
+
+struct dagnet_plan {
+    int S = 0, N = 0, K = 1, M = 0, AS = 1, n_tiles = 0, device = 0;
+    DnLds lds;
+    int32_t *d_scene_ptr = nullptr, *d_tile_u0 = nullptr, *d_tile_nu = nullptr, *d_row_scene = nullptr;
+    int64_t *d_off_dense = nullptr, *d_off_compact = nullptr;
+    double *d_loss_part = nullptr;
+    void *d_static = nullptr;   // {DnDims, DnLds, DnWeights} prefix of DnParams for this (model, plan)
+    int64_t compact_size = 0;
+    const dagnet_model *owner = nullptr;
+};
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+struct Tensor {
+    const float *p;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+typedef std::function<float(int, int)> WFn;   // (output n, input k) -> weight
+
+struct Packer {
+    std::vector<float> buf;
+    std::map<std::string, Tensor> t;
+    std::string missing;
+
+    const Tensor *get(const std::string &name, std::initializer_list<int64_t> shape) {
+        auto it = t.find(name);
+        if (it == t.end()) {
+            if (missing.empty()) missing = name;
+            return nullptr;
+        }
+        if (it->second.shape != std::vector<int64_t>(shape)) {
+            if (missing.empty()) {
+                missing = name + " (shape mismatch: got [";
+                for (auto s : it->second.shape) missing += std::to_string(s) + ",";
+                missing += "] want [";
+                for (auto s : shape) missing += std::to_string(s) + ",";
+                missing += "])";
+            }
+            return nullptr;
+        }
+        return &it->second;
+    }
+    bool has(const std::string &name) const { return t.count(name) != 0; }
+
+    int align() {
+        while (buf.size() % 4) buf.push_back(0.f);
+        return (int)buf.size();
+    }
+    // fragment-ordered segment: [nt][kg][lane 64][4]
+    int seg(const WFn &W, int N, int K) {
+        const int nt = (N + 31) / 32, kg = (K + 7) / 8;
+        const int off = align();
+        buf.resize(off + (size_t)nt * kg * 256, 0.f);
+        for (int a = 0; a < nt; ++a)
+            for (int g = 0; g < kg; ++g)
+                for (int l = 0; l < 64; ++l)
+                    for (int i = 0; i < 4; ++i) {
+                        const int n = a * 32 + (l & 31), k = g * 8 + 2 * i + (l >> 5);
+                        buf[off + (((size_t)a * kg + g) * 64 + l) * 4 + i] = (n < N && k < K) ? W(n, k) : 0.f;
+                    }
+        return off;
+    }
+    int vec(const std::function<float(int)> &f, int n, int npad) {
+        const int off = align();
+        buf.resize(off + npad, 0.f);
+        for (int i = 0; i < n; ++i) buf[off + i] = f(i);
+        return off;
+    }
+    int gather(const WFn &W, int N, int G) {
+        const int ld = pad32(N);
+        const int off = align();
+        buf.resize(off + (size_t)G * ld, 0.f);
+        for (int g = 0; g < G; ++g)
+            for (int n = 0; n < N; ++n) buf[off + (size_t)g * ld + n] = W(n, g);
+        return off;
+    }
+};
+
+struct SegSpec {
+    int col0, K;
+};
+
+// torch nn.Linear "name": weight [N][Ktot], bias [N]
+DnLin pack_linear(Packer &pk, const std::string &name, int N, int Ktot, std::vector<SegSpec> segs, int gcol0 = -1, int G = 0) {
+    DnLin L;
+    memset(&L, 0, sizeof(L));
+    L.n = N;
+    L.nt = (N + 31) / 32;
+    L.bias = L.gather = -1;
+    const Tensor *W = pk.get(name + ".weight", {N, Ktot});
+    const Tensor *B = pk.get(name + ".bias", {N});
+    if (!W || !B) return L;
+    const float *w = W->p;
+    L.nseg = (int)segs.size();
+    for (int s = 0; s < L.nseg; ++s) {
+        const int c0 = segs[s].col0;
+        L.w[s] = pk.seg([=](int n, int k) { return w[(size_t)n * Ktot + c0 + k]; }, N, segs[s].K);
+        L.kg[s] = (segs[s].K + 7) / 8;
+    }
+    const float *b = B->p;
+    L.bias = pk.vec([=](int n) { return b[n]; }, N, L.nt * 32);
+    if (gcol0 >= 0) L.gather = pk.gather([=](int n, int g) { return w[(size_t)n * Ktot + gcol0 + g]; }, N, G);
+    return L;
+}
+
+// two heads stacked: rows [0,Z) from a, [Z,2Z) from b   (mean / logvar)
+DnLin pack_pair(Packer &pk, const std::string &a, const std::string &b, int Z, int K) {
+    DnLin L;
+    memset(&L, 0, sizeof(L));
+    L.n = 2 * Z;
+    L.nt = (2 * Z + 31) / 32;
+    L.bias = L.gather = -1;
+    const Tensor *Wa = pk.get(a + ".weight", {Z, K}), *Wb = pk.get(b + ".weight", {Z, K});
+    const Tensor *Ba = pk.get(a + ".bias", {Z}), *Bb = pk.get(b + ".bias", {Z});
+    if (!Wa || !Wb || !Ba || !Bb) return L;
+    const float *wa = Wa->p, *wb = Wb->p, *ba = Ba->p, *bb = Bb->p;
+    L.nseg = 1;
+    L.w[0] = pk.seg([=](int n, int k) { return n < Z ? wa[(size_t)n * K + k] : wb[(size_t)(n - Z) * K + k]; }, 2 * Z, K);
+    L.kg[0] = (K + 7) / 8;
+    L.bias = pk.vec([=](int n) { return n < Z ? ba[n] : bb[n - Z]; }, 2 * Z, L.nt * 32);
+    return L;
+}
+
+DnRaw pack_raw_linear(Packer &pk, const std::string &name, int N, int K) {
+    DnRaw r;
+    memset(&r, 0, sizeof(r));
+    r.n = N;
+    r.k = K;
+    const Tensor *W = pk.get(name + ".weight", {N, K});
+    const Tensor *B = pk.get(name + ".bias", {N});
+    if (!W || !B) return r;
+    const float *w = W->p, *b = B->p;
+    r.w = pk.vec([=](int i) { return w[i]; }, N * K, N * K);
+    r.b = pk.vec([=](int i) { return b[i]; }, N, N);
+    return r;
+}
+
+int pack_bn(Packer &pk, const std::string &name, int n) {
+    const Tensor *g = pk.get(name + ".weight", {n}), *b = pk.get(name + ".bias", {n});
+    const Tensor *mu = pk.get(name + ".running_mean", {n}), *var = pk.get(name + ".running_var", {n});
+    if (!g || !b || !mu || !var) return -1;
+    const float *gp = g->p, *bp = b->p, *mp = mu->p, *vp = var->p;
+    return pk.vec(
+        [=](int i) {
+            const int c = i % n;
+            switch (i / n) {
+                case 0: return gp[c];
+                case 1: return bp[c];
+                case 2: return mp[c];
+                default: return sqrtf(vp[c] + 1e-5f);
+            }
+        },
+        4 * n, 4 * n);
+}
+
+DnLin empty_lin() {
+    DnLin L;
+    memset(&L, 0, sizeof(L));
+    L.bias = L.gather = -1;
+    return L;
+}
+
+DnGraph pack_graph(Packer &pk, const std::string &prefix, int kind, int nin, int nout, int F, int P) {
+    DnGraph g;
+    memset(&g, 0, sizeof(g));
+    g.kind = kind;
+    g.nin = nin;
+    g.nout = nout;
+    g.heads = g.out = g.gc1 = g.gc2 = empty_lin();
+    g.b1 = g.b2 = -1;
+    if (kind == DAGNET_GRAPH_GAT) {
+        std::vector<const float *> Wh(P), ah(P);
+        for (int p = 0; p < P; ++p) {
+            const Tensor *W = pk.get(prefix + ".attention_" + std::to_string(p) + ".W", {nin, F});
+            const Tensor *a = pk.get(prefix + ".attention_" + std::to_string(p) + ".a", {2 * F, 1});
+            if (!W || !a) return g;
+            Wh[p] = W->p;
+            ah[p] = a->p;
+        }
+        g.heads.n = P * F;
+        g.heads.nt = (P * F + 31) / 32;
+        g.heads.nseg = 1;
+        g.heads.w[0] = pk.seg([=](int n, int k) { return Wh[n / F][(size_t)k * F + (n % F)]; }, P * F, nin);
+        g.heads.kg[0] = (nin + 7) / 8;
+        g.a_heads = pk.vec([=](int i) { return ah[i / (2 * F)][i % (2 * F)]; }, P * 2 * F, P * 2 * F);
+        const Tensor *Wo = pk.get(prefix + ".out_att.W", {P * F, nout});
+        const Tensor *ao = pk.get(prefix + ".out_att.a", {2 * nout, 1});
+        if (!Wo || !ao) return g;
+        const float *wo = Wo->p, *aop = ao->p;
+        g.out.n = nout;
+        g.out.nt = (nout + 31) / 32;
+        g.out.nseg = 1;
+        g.out.w[0] = pk.seg([=](int n, int k) { return wo[(size_t)k * nout + n]; }, nout, P * F);
+        g.out.kg[0] = (P * F + 7) / 8;
+        g.a_out = pk.vec([=](int i) { return aop[i]; }, 2 * nout, 2 * nout);
+        g.bn1 = pack_bn(pk, prefix + ".bn1", nout);
+    } else if (kind == DAGNET_GRAPH_GCN) {
+        const Tensor *W1 = pk.get(prefix + ".gc1.weight", {nin, F});
+        const Tensor *W2 = pk.get(prefix + ".gc2.weight", {F, nout});
+        if (!W1 || !W2) return g;
+        const float *w1 = W1->p, *w2 = W2->p;
+        g.gc1.n = F;
+        g.gc1.nt = (F + 31) / 32;
+        g.gc1.nseg = 1;
+        g.gc1.w[0] = pk.seg([=](int n, int k) { return w1[(size_t)k * F + n]; }, F, nin);
+        g.gc1.kg[0] = (nin + 7) / 8;
+        g.gc2.n = nout;
+        g.gc2.nt = (nout + 31) / 32;
+        g.gc2.nseg = 1;
+        g.gc2.w[0] = pk.seg([=](int n, int k) { return w2[(size_t)k * nout + n]; }, nout, F);
+        g.gc2.kg[0] = (F + 7) / 8;
+        if (pk.has(prefix + ".gc1.bias")) {
+            const Tensor *b = pk.get(prefix + ".gc1.bias", {F});
+            if (b) { const float *bp = b->p; g.b1 = pk.vec([=](int i) { return bp[i]; }, F, F); }
+        }
+        if (pk.has(prefix + ".gc2.bias")) {
+            const Tensor *b = pk.get(prefix + ".gc2.bias", {nout});
+            if (b) { const float *bp = b->p; g.b2 = pk.vec([=](int i) { return bp[i]; }, nout, nout); }
+        }
+        g.bn1 = pack_bn(pk, prefix + ".bn1", F);
+        g.bn2 = pack_bn(pk, prefix + ".bn2", nout);
+    }
+    return g;
+}
+
+DnGru pack_gru(Packer &pk, int l, int R, int H) {
+    DnGru g;
+    g.r = g.z = g.ni = g.nh = empty_lin();
+    const int Kin = l == 0 ? 2 * H : R;
+    const std::string sl = std::to_string(l);
+    const Tensor *Wi = pk.get("rnn.weight_ih_l" + sl, {3 * R, Kin});
+    const Tensor *Wh = pk.get("rnn.weight_hh_l" + sl, {3 * R, R});
+    const Tensor *Bi = pk.get("rnn.bias_ih_l" + sl, {3 * R});
+    const Tensor *Bh = pk.get("rnn.bias_hh_l" + sl, {3 * R});
+    if (!Wi || !Wh || !Bi || !Bh) return g;
+    const float *wi = Wi->p, *wh = Wh->p, *bi = Bi->p, *bh = Bh->p;
+    std::vector<SegSpec> xs;
+    if (l == 0) xs = {{0, H}, {H, H}};
+    else xs = {{0, R}};
+    auto mk = [&](DnLin &L, int gate, bool with_x, bool with_h) {
+        L.n = R;
+        L.nt = (R + 31) / 32;
+        L.nseg = 0;
+        if (with_x)
+            for (auto s : xs) {
+                const int c0 = s.col0;
+                L.w[L.nseg] = pk.seg([=](int n, int k) { return wi[(size_t)(gate * R + n) * Kin + c0 + k]; }, R, s.K);
+                L.kg[L.nseg] = (s.K + 7) / 8;
+                ++L.nseg;
+            }
+        if (with_h) {
+            L.w[L.nseg] = pk.seg([=](int n, int k) { return wh[(size_t)(gate * R + n) * R + k]; }, R, R);
+            L.kg[L.nseg] = (R + 7) / 8;
+            ++L.nseg;
+        }
+        L.bias = pk.vec(
+            [=](int n) { return (with_x ? bi[gate * R + n] : 0.f) + (with_h ? bh[gate * R + n] : 0.f); }, R, L.nt * 32);
+    };
+    mk(g.r, 0, true, true);
+    mk(g.z, 1, true, true);
+    mk(g.ni, 2, true, false);
+    mk(g.nh, 2, false, true);
+    return g;
+}
+
+}   // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" const char *dagnet_last_error(void) { return g_err; }
+extern "C" const char *dagnet_version(void) { return "dagnet_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+
+extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor *tensors, int32_t n_tensors, dagnet_model **out) {
+    if (!cfg || !out || (!tensors && n_tensors > 0)) return fail(DAGNET_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const dagnet_config &c = *cfg;
+    if (c.model < 0 || c.model > 3) return fail(DAGNET_ERR_INVALID, "unknown model %d", c.model);
+    if (c.x_dim < 1 || c.h_dim < 1 || c.z_dim < 1 || c.rnn_dim < 1) return fail(DAGNET_ERR_INVALID, "dims must be positive");
+    if (c.x_dim != 2 && c.model != DAGNET_MODEL_VRNN && c.model != DAGNET_MODEL_GRAPH)
+        return fail(DAGNET_ERR_INVALID, "graph models need x_dim == 2 (positions are xy), got %d", c.x_dim);
+    if (c.n_layers < 1 || c.n_layers > DN_MAX_LAYERS) return fail(DAGNET_ERR_INVALID, "n_layers must be 1..%d", DN_MAX_LAYERS);
+    const bool graph = c.model != DAGNET_MODEL_VRNN;
+    if (graph) {
+        if (c.graph_model != DAGNET_GRAPH_GAT && c.graph_model != DAGNET_GRAPH_GCN)
+            return fail(DAGNET_ERR_INVALID, "graph_model must be gat or gcn");
+        if (c.graph_hid < 1 || c.graph_hid > DN_FCAP) return fail(DAGNET_ERR_INVALID, "graph_hid must be 1..%d", DN_FCAP);
+        if (c.graph_model == DAGNET_GRAPH_GAT && c.n_heads < 1) return fail(DAGNET_ERR_INVALID, "n_heads must be >= 1");
+        if (c.adjacency_type < 0 || c.adjacency_type > 2) return fail(DAGNET_ERR_INVALID, "adjacency_type must be 0,1,2");
+        if (c.adjacency_type == 2 && c.top_k_neigh < 1)
+            return fail(DAGNET_ERR_INVALID, "Using KNN-similarity but top_k_neigh is not specified");
+    }
+    if (c.model == DAGNET_MODEL_DAGNET && (c.g_dim < 1 || c.n_max_agents < 1))
+        return fail(DAGNET_ERR_INVALID, "DAG-Net needs g_dim and n_max_agents");
+
+    Packer pk;
+    for (int i = 0; i < n_tensors; ++i) {
+        Tensor t;
+        t.p = tensors[i].h_data;
+        for (int d = 0; d < tensors[i].ndim; ++d) t.shape.push_back(tensors[i].shape[d]);
+        if (!tensors[i].name || !t.p) return fail(DAGNET_ERR_INVALID, "tensor %d has a null name or data", i);
+        pk.t[tensors[i].name] = t;
+    }
+    dagnet_model *m = new dagnet_model();
+    m->cfg = c;
+    DnDims &D = m->dims;
+    memset(&D, 0, sizeof(D));
+    D.model = c.model;
+    D.graph = graph ? c.graph_model : 0;
+    D.adj_type = c.adjacency_type;
+    D.knn_k = c.top_k_neigh;
+    D.X = c.x_dim; D.H = c.h_dim; D.Z = c.z_dim; D.R = c.rnn_dim; D.L = c.n_layers;
+    D.G = c.model == DAGNET_MODEL_DAGNET ? c.g_dim : 0;
+    D.D = c.model == DAGNET_MODEL_DAGNET ? 2 * c.n_max_agents : 0;
+    D.F = graph ? c.graph_hid : 0;
+    D.P = graph && c.graph_model == DAGNET_GRAPH_GAT ? c.n_heads : 0;
+    D.sigma = c.sigma;
+    D.alpha = c.alpha;
+    const int X = D.X, H = D.H, Z = D.Z, R = D.R, G = D.G, Dd = D.D;
+    const bool dag = c.model == DAGNET_MODEL_DAGNET;
+
+    DnWeights &W = m->w;
+    memset(&W, 0, sizeof(W));
+    if (c.model == DAGNET_MODEL_GRAPH) {
+        // stand-alone GAT / GCN module: rnn_dim = nin, h_dim = nout, state-dict prefix "graph"
+        W.g_hid = pack_graph(pk, "graph", D.graph, R, H, D.F, D.P);
+    } else {
+    W.phi_x0 = pack_raw_linear(pk, "phi_x.0", H, X);
+    W.phi_x2 = pack_linear(pk, "phi_x.2", H, H, {{0, H}});
+    W.phi_z0 = pack_linear(pk, "phi_z.0", H, Z, {{0, Z}});
+    W.phi_z2 = pack_linear(pk, "phi_z.2", H, H, {{0, H}});
+    if (dag) {
+        W.enc0 = pack_linear(pk, "enc.0", H, H + G + R, {{0, H}, {H + G, R}}, H, G);
+        W.prior0 = pack_linear(pk, "prior.0", H, G + R, {{G, R}}, 0, G);
+        W.dec0 = pack_linear(pk, "dec.0", H, Dd + G + H + R, {{0, Dd}, {Dd + G, H}, {Dd + G + H, R}}, Dd, G);
+    } else {
+        W.enc0 = pack_linear(pk, "enc.0", H, H + R, {{0, H}, {H, R}});
+        W.prior0 = pack_linear(pk, "prior.0", H, R, {{0, R}});
+        W.dec0 = pack_linear(pk, "dec.0", H, H + R, {{0, H}, {H, R}});
+    }
+    W.enc2 = pack_linear(pk, "enc.2", H, H, {{0, H}});
+    W.enc_ml = pack_pair(pk, "enc_mean", "enc_logvar", Z, H);
+    W.prior2 = pack_linear(pk, "prior.2", H, H, {{0, H}});
+    W.prior_ml = pack_pair(pk, "prior_mean", "prior_logvar", Z, H);
+    W.dec2 = pack_linear(pk, "dec.2", H, H, {{0, H}});
+    W.dec_mean = pack_raw_linear(pk, "dec_mean", X, H);
+    W.dec_logvar = pack_raw_linear(pk, "dec_logvar", X, H);
+    for (int l = 0; l < D.L; ++l) W.gru[l] = pack_gru(pk, l, R, H);
+    if (graph) {
+        W.g_hid = pack_graph(pk, dag ? "graph_hiddens" : "graph", D.graph, R, R, D.F, D.P);
+        W.blend = pack_linear(pk, dag ? "lg_hiddens" : "lg", R, 2 * R, {{0, R}, {R, R}});
+    }
+    if (dag) {
+        W.dec_goal0 = pack_linear(pk, "dec_goal.0", H, Dd + R + G, {{0, Dd}, {Dd, R}}, Dd + R, G);
+        W.dec_goal2 = pack_linear(pk, "dec_goal.2", G, H, {{0, H}});
+        W.g_goal = pack_graph(pk, "graph_goals", D.graph, G, G, D.F, D.P);
+        W.lg_goals = pack_linear(pk, "lg_goals.0", G, 2 * G, {{0, G}, {G, G}});
+    }
+    }
+    if (!pk.missing.empty()) {
+        const int rc = fail(DAGNET_ERR_MISSING, "state dict entry missing or mis-shaped: %s", pk.missing.c_str());
+        delete m;
+        return rc;
+    }
+    pk.align();
+    m->wp_floats = pk.buf.size();
+    hipError_t e = hipGetDevice(&m->device);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_wp), m->wp_floats * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpy(m->d_wp, pk.buf.data(), m->wp_floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        if (m->d_wp) (void)hipFree(m->d_wp);
+        delete m;
+        return fail(DAGNET_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return DAGNET_OK;
+}
+
+extern "C" void dagnet_model_destroy(dagnet_model *m) {
+    if (!m) return;
+    if (m->d_wp) (void)hipFree(m->d_wp);
+    delete m;
+}
+
+// LDS layout for tile height M; returns total floats
+static DnLds make_layout(const DnDims &D, int M, int AS) {
+    DnLds L;
+    memset(&L, 0, sizeof(L));
+    L.M = M;
+    L.AS = AS;
+    const int TW = std::max(std::max(pad32(D.H), pad32(D.R)), pad32(2 * D.Z));
+    const int Hp = pad32(D.H), Rp = pad32(D.R);
+    int off = 0;
+    auto take = [&](int floats) {
+        const int o = off;
+        off += (floats + 3) & ~3;
+        return o;
+    };
+    for (int l = 0; l < D.L; ++l) L.h[l] = take(Rp * M);
+    L.t1 = take(TW * M);
+    const bool graph = D.model != 0, dag = D.model == 2;
+    if (dag) L.d = take(pad8(D.D) * M);
+    if (graph) {
+        const int gw = pad32(std::max(D.P * D.F, D.F));
+        L.wh = take(gw * M);
+        L.x2 = take(gw * M);
+        L.adj = take(M * AS);
+        L.att = take(M * AS);
+        L.s12 = take(2 * std::max(D.P, 1) * M);
+    }
+    L.red = take(2 * DN_THREADS);
+    L.xabs = take(2 * M);
+    L.dm = take(2 * D.X * M);
+    L.xt = take(D.X * M);
+    L.ri = take(7 * M);
+    const int u0 = off;
+    L.t2 = u0;
+    L.t3 = u0 + TW * M;
+    L.px = u0 + 2 * TW * M;
+    L.pz = L.px + Hp * M;
+    int usize = (2 * TW + 2 * Hp) * M;
+    if (dag) {
+        const int Gp = pad32(D.G);
+        L.decg = u0;
+        L.gg = u0 + Gp * M;
+        L.gcomb = u0 + 2 * Gp * M;
+        usize = std::max(usize, 3 * Gp * M);
+    }
+    off += usize;
+    L.total = std::max(off, 3 * DN_THREADS * 2);   // room for the fp64 loss reduction at offset 0
+    return L;
+}
+
+static const int64_t kLdsBudgetBytes = 160 * 1024;
+
+extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_ptr, int32_t S, int32_t K, dagnet_plan **out) {
+    if (!h_scene_ptr || !out) return fail(DAGNET_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (S < 1 || K < 1) return fail(DAGNET_ERR_INVALID, "need at least one scene and one sample");
+    if (h_scene_ptr[0] != 0) return fail(DAGNET_ERR_INVALID, "scene_ptr[0] must be 0");
+    int nmax = 0;
+    for (int s = 0; s < S; ++s) {
+        const int n = h_scene_ptr[s + 1] - h_scene_ptr[s];
+        if (n < 1) return fail(DAGNET_ERR_INVALID, "scene %d is empty or scene_ptr is not increasing", s);
+        nmax = std::max(nmax, n);
+    }
+    const int N = h_scene_ptr[S];
+    if ((int64_t)N * K > 0x7fffffffLL) return fail(DAGNET_ERR_INVALID, "N*K exceeds 2^31 rows; shard the batch");
+    if (m && m->dims.model == DAGNET_MODEL_DAGNET && 2 * nmax > m->dims.D)
+        return fail(DAGNET_ERR_INVALID, "scene with %d agents exceeds n_max_agents=%d", nmax, m->dims.D / 2);
+    // tile height: 64 rows when it fits the LDS, else 32; scenes must fit a tile
+    int M = 0;
+    DnLds L;
+    const int cand[4] = {64, 32, 128, 256};
+    memset(&L, 0, sizeof(L));
+    for (int i = 0; m && i < 4 && !M; ++i) {
+        if (cand[i] < nmax) continue;
+        L = make_layout(m->dims, cand[i], nmax);
+        if ((int64_t)L.total * 4 <= kLdsBudgetBytes) M = cand[i];
+    }
+    if (m && !M)
+        return fail(DAGNET_ERR_CAPACITY,
+                    "no tile height fits: largest scene has %d agents, model needs %lld B of LDS at the smallest usable tile "
+                    "(budget %lld B)",
+                    nmax, (long long)make_layout(m->dims, std::max(32, pad32(nmax)), nmax).total * 4, (long long)kLdsBudgetBytes);
+
+    std::vector<int32_t> u0, nu, row_scene(N);
+    std::vector<int64_t> offd(S), offc(S);
+    int64_t acc = 0;
+    for (int s = 0; s < S; ++s) {
+        const int b = h_scene_ptr[s], n = h_scene_ptr[s + 1] - b;
+        for (int i = 0; i < n; ++i) row_scene[b + i] = s;
+        offd[s] = (int64_t)b * N + b;
+        offc[s] = acc;
+        acc += (int64_t)n * n;
+    }
+    const int64_t units = (int64_t)S * K;
+    int64_t u = 0;
+    while (m && u < units) {
+        int rows = 0, cnt = 0;
+        while (u + cnt < units) {
+            const int s = (int)((u + cnt) % S);
+            const int n = h_scene_ptr[s + 1] - h_scene_ptr[s];
+            if (rows + n > M) break;
+            rows += n;
+            ++cnt;
+        }
+        u0.push_back((int32_t)u);
+        nu.push_back(cnt);
+        u += cnt;
+    }
+    dagnet_plan *p = new dagnet_plan();
+    p->S = S; p->N = N; p->K = K; p->M = M; p->AS = nmax; p->lds = L;
+    p->owner = m;
+    p->n_tiles = (int)u0.size();
+    p->compact_size = acc;
+    hipError_t e = hipGetDevice(&p->device);
+    auto up = [&](void **dst, const void *src, size_t bytes) {
+        if (e != hipSuccess) return;
+        e = hipMalloc(dst, bytes);
+        if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+    };
+    up(reinterpret_cast<void **>(&p->d_scene_ptr), h_scene_ptr, sizeof(int32_t) * (S + 1));
+    if (m) {
+        up(reinterpret_cast<void **>(&p->d_tile_u0), u0.data(), sizeof(int32_t) * u0.size());
+        up(reinterpret_cast<void **>(&p->d_tile_nu), nu.data(), sizeof(int32_t) * nu.size());
+    }
+    up(reinterpret_cast<void **>(&p->d_row_scene), row_scene.data(), sizeof(int32_t) * N);
+    up(reinterpret_cast<void **>(&p->d_off_dense), offd.data(), sizeof(int64_t) * S);
+    up(reinterpret_cast<void **>(&p->d_off_compact), offc.data(), sizeof(int64_t) * S);
+    if (m && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_loss_part), sizeof(double) * 3 * p->n_tiles);
+    if (m) {
+        DnParams P;
+        memset(&P, 0, sizeof(P));
+        P.d = m->dims;
+        P.l = L;
+        P.w = m->w;
+        up(&p->d_static, &P, offsetof(DnParams, r));
+    }
+    if (e != hipSuccess) {
+        dagnet_plan_destroy(p);
+        return fail(DAGNET_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
+    }
+    *out = p;
+    return DAGNET_OK;
+}
+
+extern "C" void dagnet_plan_destroy(dagnet_plan *p) {
+    if (!p) return;
+    void *ptrs[] = {p->d_scene_ptr, p->d_tile_u0, p->d_tile_nu, p->d_row_scene, p->d_off_dense, p->d_off_compact, p->d_loss_part, p->d_static};
+    for (void *q : ptrs)
+        if (q) (void)hipFree(q);
+    delete p;
+}
+
+extern "C" int dagnet_plan_info(const dagnet_plan *p, int32_t *tile_rows, int32_t *n_tiles, int64_t *lds_bytes) {
+    if (!p) return fail(DAGNET_ERR_INVALID, "null plan");
+    if (tile_rows) *tile_rows = p->M;
+    if (n_tiles) *n_tiles = p->n_tiles;
+    if (lds_bytes) *lds_bytes = (int64_t)p->lds.total * 4;
+    return DAGNET_OK;
+}
+
+static int check_plan(const dagnet_model *m, const dagnet_plan *p) {
+    if (!p->d_static || p->n_tiles < 1) return fail(DAGNET_ERR_INVALID, "plan was created without a model (tables only)");
+    if (p->owner != m) return fail(DAGNET_ERR_INVALID, "plan was created for another model");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev != p->device || dev != m->device)
+        return fail(DAGNET_ERR_INVALID, "model/plan belong to device %d/%d but device %d is current", m->device, p->device, dev);
+    return DAGNET_OK;
+}
+
+static void fill_common(DnParams &P, const dagnet_model *m, const dagnet_plan *p) {
+    memset(&P, 0, sizeof(P));
+    P.d = m->dims;
+    P.l = p->lds;
+    P.w = m->w;
+    P.r.wp = m->d_wp;
+    P.r.scene_ptr = p->d_scene_ptr;
+    P.r.tile_u0 = p->d_tile_u0;
+    P.r.tile_nu = p->d_tile_nu;
+    P.r.S = p->S;
+    P.r.N = p->N;
+    P.r.K = p->K;
+    P.r.n_tiles = p->n_tiles;
+}
+
+extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_h0, const float *d_x0,
+                             const int32_t *d_g0, const float *d_eps, const float *d_q, const int32_t *d_force_goals, uint64_t seed,
+                             float *d_out, int32_t *d_out_goals, void *stream) {
+    if (!m || !p || !d_h0 || !d_out) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (T < 0) return fail(DAGNET_ERR_INVALID, "T must be >= 0");
+    if (m->dims.model == DAGNET_MODEL_GRAPH) return fail(DAGNET_ERR_INVALID, "stand-alone graph modules have no sample()");
+    if (m->dims.model != DAGNET_MODEL_VRNN && !d_x0) return fail(DAGNET_ERR_INVALID, "x_abs_start is required for graph models");
+    if (m->dims.model == DAGNET_MODEL_DAGNET && !d_g0) return fail(DAGNET_ERR_INVALID, "g_start is required for DAG-Net");
+    if (m->dims.model == DAGNET_MODEL_DAGNET && 2 * p->AS > m->dims.D) return fail(DAGNET_ERR_INVALID, "plan was made for another model");
+    if (T == 0) return DAGNET_OK;
+    if (int rc = check_plan(m, p)) return rc;
+    DnParams P;
+    fill_common(P, m, p);
+    P.r.T = T;
+    P.r.h0 = d_h0; P.r.x0 = d_x0; P.r.g0 = d_g0;
+    P.r.eps = d_eps; P.r.q = d_q; P.r.force_goals = d_force_goals;
+    P.r.seed = seed;
+    P.r.out = d_out; P.r.out_goals = d_out_goals;
+    HIP_TRY(dn_launch_rollout(0, p->d_static, &P.r, (size_t)p->lds.total * 4, static_cast<hipStream_t>(stream)));
+    return DAGNET_OK;
+}
+
+static int set_adj(DnParams &P, const dagnet_plan *p, const float *d_adj, int64_t adj_dense_ld) {
+    if (!d_adj) return fail(DAGNET_ERR_INVALID, "adjacency is required for graph models");
+    if (adj_dense_ld != 0 && adj_dense_ld != p->N) return fail(DAGNET_ERR_INVALID, "adj_dense_ld must be 0 (compact) or N");
+    P.r.adj = d_adj;
+    P.r.adj_ld = adj_dense_ld;
+    P.r.adj_tstride = adj_dense_ld ? (int64_t)p->N * p->N : p->compact_size;
+    P.r.adj_off = adj_dense_ld ? p->d_off_dense : p->d_off_compact;
+    return DAGNET_OK;
+}
+
+extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_traj, const float *d_traj_rel,
+                              const int32_t *d_goals, const float *d_adj, int64_t adj_dense_ld, const float *d_eps, uint64_t seed,
+                              double *d_losses, float *d_h_out, void *stream) {
+    if (!m || !p || !d_traj_rel || !d_losses || !d_h_out) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (p->K != 1) return fail(DAGNET_ERR_INVALID, "forward needs a plan with n_samples == 1");
+    if (T < 1) return fail(DAGNET_ERR_INVALID, "T must be >= 1");
+    if (m->dims.model == DAGNET_MODEL_GRAPH) return fail(DAGNET_ERR_INVALID, "stand-alone graph modules have no forward pass");
+    const bool dag = m->dims.model == DAGNET_MODEL_DAGNET;
+    if (dag && (!d_traj || !d_goals)) return fail(DAGNET_ERR_INVALID, "traj and goals are required for DAG-Net");
+    if (int rc = check_plan(m, p)) return rc;
+    DnParams P;
+    fill_common(P, m, p);
+    if (m->dims.model != DAGNET_MODEL_VRNN) {
+        const int rc = set_adj(P, p, d_adj, adj_dense_ld);
+        if (rc) return rc;
+    }
+    P.r.T = T;
+    P.r.traj = d_traj; P.r.traj_rel = d_traj_rel; P.r.goals = d_goals;
+    P.r.eps = d_eps;
+    P.r.seed = seed;
+    P.r.loss_part = p->d_loss_part;
+    P.r.h_out = d_h_out;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    HIP_TRY(dn_launch_rollout(1, p->d_static, &P.r, (size_t)p->lds.total * 4, st));
+    HIP_TRY(dn_launch_loss_finalize(p->n_tiles, p->N, p->d_loss_part, d_losses, st));
+    return DAGNET_OK;
+}
+
+extern "C" int dagnet_graph_forward(const dagnet_model *m, const dagnet_plan *p, int32_t which, const float *d_x, const float *d_adj,
+                                    int64_t adj_dense_ld, float *d_out, void *stream) {
+    if (!m || !p || !d_x || !d_out) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (p->K != 1) return fail(DAGNET_ERR_INVALID, "graph_forward needs a plan with n_samples == 1");
+    if (m->dims.model == DAGNET_MODEL_VRNN) return fail(DAGNET_ERR_INVALID, "VRNN has no graph");
+    if (which != 0 && !(which == 1 && m->dims.model == DAGNET_MODEL_DAGNET)) return fail(DAGNET_ERR_INVALID, "no such graph: %d", which);
+    if (int rc = check_plan(m, p)) return rc;
+    DnParams P;
+    fill_common(P, m, p);
+    const int rc = set_adj(P, p, d_adj, adj_dense_ld);
+    if (rc) return rc;
+    P.r.gx = d_x;
+    P.r.gout = d_out;
+    P.r.gwhich = which;
+    HIP_TRY(dn_launch_rollout(2, p->d_static, &P.r, (size_t)p->lds.total * 4, static_cast<hipStream_t>(stream)));
+    return DAGNET_OK;
+}
+
+extern "C" int dagnet_adjacency(const dagnet_plan *p, int32_t adjacency_type, float sigma, int32_t top_k, int32_t T, const float *d_pos,
+                                float *d_out, int64_t dense_ld, void *stream) {
+    if (!p || !d_out) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (adjacency_type < 0 || adjacency_type > 2) return fail(DAGNET_ERR_INVALID, "adjacency_type must be 0,1,2");
+    if (adjacency_type != 0 && !d_pos) return fail(DAGNET_ERR_INVALID, "positions are required");
+    if (adjacency_type == 2 && top_k < 1) return fail(DAGNET_ERR_INVALID, "top_k must be >= 1");
+    if (dense_ld != 0 && dense_ld != p->N) return fail(DAGNET_ERR_INVALID, "dense_ld must be 0 (compact) or N");
+    if (T < 1) return DAGNET_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t tstride = dense_ld ? (int64_t)p->N * p->N : p->compact_size;
+    if (dense_ld) HIP_TRY(hipMemsetAsync(d_out, 0, sizeof(float) * tstride * T, st));
+    HIP_TRY(dn_launch_adjacency(adjacency_type, sigma, top_k, p->d_scene_ptr, p->d_row_scene, dense_ld ? p->d_off_dense : p->d_off_compact,
+                                p->N, T, d_pos, d_out, dense_ld, tstride, st));
+    return DAGNET_OK;
+}
+
+extern "C" int64_t dagnet_plan_compact_adj_size(const dagnet_plan *p) { return p ? p->compact_size : -1; }
+
+extern "C" int dagnet_best_of_k(const dagnet_plan *p, int32_t K, int32_t T, const float *d_samples_rel, const float *d_start,
+                                const float *d_gt, float *d_ade_raw, float *d_fde_raw, float *d_scene_best, double *d_sums, void *stream) {
+    if (!p || !d_samples_rel || !d_start || !d_gt || !d_ade_raw || !d_fde_raw || !d_scene_best || !d_sums)
+        return fail(DAGNET_ERR_INVALID, "null argument");
+    if (K < 1 || T < 1) return fail(DAGNET_ERR_INVALID, "K and T must be >= 1");
+    HIP_TRY(dn_launch_best_of_k(p->d_scene_ptr, p->S, p->N, K, T, d_samples_rel, d_start, d_gt, d_ade_raw, d_fde_raw, d_scene_best, d_sums,
+                                static_cast<hipStream_t>(stream)));
+    return DAGNET_OK;
+}
+
+extern "C" int dagnet_relative_to_abs(int32_t T, int32_t N, const float *d_rel, const float *d_start, float *d_out, void *stream) {
+    if (!d_rel || !d_start || !d_out) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (T < 0 || N < 0) return fail(DAGNET_ERR_INVALID, "negative size");
+    HIP_TRY(dn_launch_rel_to_abs(T, N, d_rel, d_start, d_out, static_cast<hipStream_t>(stream)));
+    return DAGNET_OK;
+}
+
+extern "C" int dagnet_categorical(int32_t N, int32_t G, const float *d_weights, const float *d_q, uint64_t seed, int32_t *d_out,
+                                  void *stream) {
+    if (!d_weights || !d_out) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (N < 0 || G < 1) return fail(DAGNET_ERR_INVALID, "need G >= 1");
+    HIP_TRY(dn_launch_categorical(N, G, d_weights, d_q, seed, d_out, static_cast<hipStream_t>(stream)));
+    return DAGNET_OK;
+}
+
+extern "C" int dagnet_displacement_errors(int32_t T, int32_t N, const float *d_pred, const float *d_gt, float *d_ade, float *d_fde,
+                                          void *stream) {
+    if (!d_pred || !d_gt || !d_ade || !d_fde) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (T < 1 || N < 0) return fail(DAGNET_ERR_INVALID, "need T >= 1");
+    HIP_TRY(dn_launch_abs_errors(T, N, d_pred, d_gt, d_ade, d_fde, static_cast<hipStream_t>(stream)));
+    return DAGNET_OK;
+}
+
+extern "C" int dagnet_scene_min_sum(const dagnet_plan *p, int32_t K, const float *d_ade_raw, const float *d_fde_raw, float *d_scene_best,
+                                    double *d_sums, void *stream) {
+    if (!p || !d_ade_raw || !d_fde_raw || !d_scene_best || !d_sums) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (K < 1) return fail(DAGNET_ERR_INVALID, "K must be >= 1");
+    HIP_TRY(dn_launch_scene_min_sum(p->d_scene_ptr, p->S, p->N, K, d_ade_raw, d_fde_raw, d_scene_best, d_sums,
+                                    static_cast<hipStream_t>(stream)));
+    return DAGNET_OK;
+}

@@ -1,0 +1,229 @@
+// Small HBM-bound kernels either side of the rollout: adjacency tensors for the teacher-forced
+// pass, best-of-K metrics, loss finalisation.
+// Reference behaviour: models/utils/adjacency_matrix.py:21-28,49-58,86-103,108-152,
+// models/utils/utils.py:8-21,76-111,290-302, models/dagnet/evaluate_bsk.py:71-82,115-127.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include "rng.h"
+
+// one thread per (t, row): writes the row's adjacency to all members of its scene
+__global__ void dn_adjacency_kernel(int type, float sigma, int top_k, const int32_t *__restrict__ scene_ptr,
+                                    const int32_t *__restrict__ row_scene, const int64_t *__restrict__ blk_off,
+                                    int N, int T, const float *__restrict__ pos, float *__restrict__ out,
+                                    int64_t ld, int64_t tstride) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * T) return;
+    const int t = (int)(idx / N), i = (int)(idx - (int64_t)t * N);
+    const int s = row_scene[i];
+    const int b = scene_ptr[s], n = scene_ptr[s + 1] - b;
+    const int64_t rld = ld > 0 ? ld : (int64_t)n;
+    float *o = out + (int64_t)t * tstride + blk_off[s] + (int64_t)(i - b) * rld;
+    if (type == 0) {
+        for (int j = 0; j < n; ++j) o[j] = 1.0f;
+        return;
+    }
+    const float *p = pos + (int64_t)t * N * 2;
+    const double xi = (double)p[i * 2], yi = (double)p[i * 2 + 1];
+    if (type == 1) {
+        for (int j = 0; j < n; ++j) {
+            const double dx = xi - (double)p[(b + j) * 2], dy = yi - (double)p[(b + j) * 2 + 1];
+            o[j] = (float)exp(-sqrt(dx * dx + dy * dy) / (double)sigma);
+        }
+    } else {
+        const int k = top_k < n ? top_k : n;
+        for (int j = 0; j < n; ++j) {
+            const double dx = xi - (double)p[(b + j) * 2], dy = yi - (double)p[(b + j) * 2 + 1];
+            const double d = dx * dx + dy * dy;
+            int rank = 0;
+            for (int j2 = 0; j2 < n; ++j2) {
+                const double ex = xi - (double)p[(b + j2) * 2], ey = yi - (double)p[(b + j2) * 2 + 1];
+                const double d2 = ex * ex + ey * ey;
+                rank += (d2 < d || (d2 == d && j2 < j)) ? 1 : 0;
+            }
+            o[j] = rank < k ? 1.0f : 0.0f;
+        }
+    }
+}
+
+// one thread per (k, row): abs = cumsum(rel) + start; ade = sum_t |gt - abs|, fde = |gt_T - abs_T|
+__global__ void dn_displacement_errors_kernel(int N, int K, int T, const float2 *__restrict__ rel,
+                                              const float2 *__restrict__ start, const float2 *__restrict__ gt,
+                                              float *__restrict__ ade, float *__restrict__ fde) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * K) return;
+    const int k = (int)(idx / N), n = (int)(idx - (int64_t)k * N);
+    const float2 s = start[n];
+    float cx = 0.f, cy = 0.f, a = 0.f, f = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float2 r = rel[((int64_t)k * T + t) * N + n];
+        cx += r.x;
+        cy += r.y;
+        const float2 g = gt[(int64_t)t * N + n];
+        const float dx = g.x - (cx + s.x), dy = g.y - (cy + s.y);
+        f = sqrtf(dx * dx + dy * dy);
+        a += f;
+    }
+    ade[idx] = a;
+    fde[idx] = f;
+}
+
+// one thread per scene: min over K of the scene-summed error (ADE and FDE independently)
+__global__ void dn_scene_min_kernel(const int32_t *__restrict__ scene_ptr, int S, int N, int K,
+                                    const float *__restrict__ ade, const float *__restrict__ fde,
+                                    float *__restrict__ scene_best) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    const int b = scene_ptr[s], e = scene_ptr[s + 1];
+    float ba = INFINITY, bf = INFINITY;
+    for (int k = 0; k < K; ++k) {
+        float sa = 0.f, sf = 0.f;
+        for (int i = b; i < e; ++i) {
+            sa += ade[(int64_t)k * N + i];
+            sf += fde[(int64_t)k * N + i];
+        }
+        ba = fminf(ba, sa);
+        bf = fminf(bf, sf);
+    }
+    scene_best[2 * s] = ba;
+    scene_best[2 * s + 1] = bf;
+}
+
+// single workgroup, fixed order: sums[c] = sum_s scene_best[s][c] in fp64
+__global__ void dn_sum_pairs_kernel(int S, const float *__restrict__ v, double *__restrict__ sums) {
+    __shared__ double red[2][256];
+    double a = 0.0, f = 0.0;
+    for (int s = threadIdx.x; s < S; s += 256) {
+        a += (double)v[2 * s];
+        f += (double)v[2 * s + 1];
+    }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = f;
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        double t = 0.0;
+        for (int i = 0; i < 256; ++i) t += red[threadIdx.x][i];
+        sums[threadIdx.x] = t;
+    }
+}
+
+// losses[0] = KLD, [1] = NLL (per-step means over the N rows, summed over steps), [2] = CE (sum)
+__global__ void dn_loss_finalize_kernel(int n_tiles, int N, const double *__restrict__ part, double *__restrict__ losses) {
+    if (threadIdx.x < 3) {
+        double t = 0.0;
+        for (int i = 0; i < n_tiles; ++i) t += part[(int64_t)i * 3 + threadIdx.x];
+        losses[threadIdx.x] = threadIdx.x < 2 ? t / (double)N : t;
+    }
+}
+
+// abs[t] = start + cumsum_t(rel)   (models/utils/utils.py:8-21); one thread per row
+__global__ void dn_rel_to_abs_kernel(int T, int N, const float2 *__restrict__ rel, const float2 *__restrict__ start,
+                                     float2 *__restrict__ out) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float2 s = start[n];
+    float cx = 0.f, cy = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float2 r = rel[(int64_t)t * N + n];
+        cx += r.x;
+        cy += r.y;
+        out[(int64_t)t * N + n] = make_float2(cx + s.x, cy + s.y);
+    }
+}
+
+// categorical draw the way torch.multinomial(w, 1) does it: argmax_g w[g] / q[g], q ~ Exp(1)
+// (models/utils/utils.py:200-207); one wave per row, first maximum wins
+__global__ void dn_categorical_kernel(int N, int G, const float *__restrict__ w, const float *__restrict__ q, uint64_t seed,
+                                      int32_t *__restrict__ out) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int g = lane; g < G; g += 64) {
+        const float qq = q ? q[(int64_t)row * G + g] : rng_exp1(seed, (uint32_t)row, 0u, (uint32_t)g);
+        const float v = w[(int64_t)row * G + g] / qq;
+        if (v > best) { best = v; bi = g; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) out[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
+// raw ADE/FDE of absolute trajectories (models/utils/utils.py:76-111, mode='raw'); one thread per agent
+__global__ void dn_abs_errors_kernel(int T, int N, const float2 *__restrict__ pred, const float2 *__restrict__ gt,
+                                     float *__restrict__ ade, float *__restrict__ fde) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float a = 0.f, f = 0.f;
+    for (int t = 0; t < T; ++t) {
+        const float2 p = pred[(int64_t)t * N + n], g = gt[(int64_t)t * N + n];
+        const float dx = g.x - p.x, dy = g.y - p.y;
+        f = sqrtf(dx * dx + dy * dy);
+        a += f;
+    }
+    ade[n] = a;
+    fde[n] = f;
+}
+
+extern "C" hipError_t dn_launch_abs_errors(int T, int N, const float *pred, const float *gt, float *ade, float *fde, hipStream_t st) {
+    if (N > 0)
+        hipLaunchKernelGGL(dn_abs_errors_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, T, N,
+                           reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(gt), ade, fde);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dn_launch_rel_to_abs(int T, int N, const float *rel, const float *start, float *out, hipStream_t st) {
+    if (N > 0)
+        hipLaunchKernelGGL(dn_rel_to_abs_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, T, N,
+                           reinterpret_cast<const float2 *>(rel), reinterpret_cast<const float2 *>(start),
+                           reinterpret_cast<float2 *>(out));
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dn_launch_categorical(int N, int G, const float *w, const float *q, uint64_t seed, int32_t *out, hipStream_t st) {
+    if (N > 0) hipLaunchKernelGGL(dn_categorical_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, st, N, G, w, q, seed, out);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dn_launch_adjacency(int type, float sigma, int top_k, const int32_t *scene_ptr, const int32_t *row_scene,
+                                          const int64_t *blk_off, int N, int T, const float *pos, float *out, int64_t ld,
+                                          int64_t tstride, hipStream_t st) {
+    const int64_t total = (int64_t)N * T;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(dn_adjacency_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, type, sigma, top_k,
+                       scene_ptr, row_scene, blk_off, N, T, pos, out, ld, tstride);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dn_launch_best_of_k(const int32_t *scene_ptr, int S, int N, int K, int T, const float *rel,
+                                          const float *start, const float *gt, float *ade, float *fde, float *scene_best,
+                                          double *sums, hipStream_t st) {
+    const int64_t total = (int64_t)N * K;
+    if (total > 0)
+        hipLaunchKernelGGL(dn_displacement_errors_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, N, K, T,
+                           reinterpret_cast<const float2 *>(rel), reinterpret_cast<const float2 *>(start),
+                           reinterpret_cast<const float2 *>(gt), ade, fde);
+    if (S > 0)
+        hipLaunchKernelGGL(dn_scene_min_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, scene_ptr, S, N, K, ade,
+                           fde, scene_best);
+    hipLaunchKernelGGL(dn_sum_pairs_kernel, dim3(1), dim3(256), 0, st, S, scene_best, sums);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dn_launch_scene_min_sum(const int32_t *scene_ptr, int S, int N, int K, const float *ade, const float *fde,
+                                              float *scene_best, double *sums, hipStream_t st) {
+    if (S > 0)
+        hipLaunchKernelGGL(dn_scene_min_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, scene_ptr, S, N, K, ade,
+                           fde, scene_best);
+    hipLaunchKernelGGL(dn_sum_pairs_kernel, dim3(1), dim3(256), 0, st, S, scene_best, sums);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dn_launch_loss_finalize(int n_tiles, int N, const double *part, double *losses, hipStream_t st) {
+    hipLaunchKernelGGL(dn_loss_finalize_kernel, dim3(1), dim3(64), 0, st, n_tiles, N, part, losses);
+    return hipGetLastError();
+}

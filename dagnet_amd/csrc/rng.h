@@ -1,0 +1,34 @@
+// Counter-based RNG shared by the rollout and the stand-alone categorical draw.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---------------------------------------------------------------------------------------------
+// Philox4x32-10 counter RNG (throughput mode; parity mode injects eps / q instead)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+        k.x += 0x9E3779B9u;
+        k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+// stream 0: eps (uniform [0,1)), stream 1: q (Exp(1)); element j of (row, t)
+__device__ __forceinline__ uint32_t rng_bits(uint64_t seed, uint32_t stream, uint32_t row, uint32_t t, uint32_t j) {
+    uint4 c = make_uint4(row, t, j >> 2, stream);
+    uint4 r = philox4x32_10(c, make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    const uint32_t s = j & 3u;
+    return s == 0 ? r.x : s == 1 ? r.y : s == 2 ? r.z : r.w;
+}
+__device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t row, uint32_t t, uint32_t j) {
+    return (float)(rng_bits(seed, 0, row, t, j) >> 8) * (1.0f / 16777216.0f);
+}
+__device__ __forceinline__ float rng_exp1(uint64_t seed, uint32_t row, uint32_t t, uint32_t j) {
+    const float u = ((float)(rng_bits(seed, 1, row, t, j) >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
+    return -logf(u) + 1e-30f;
+}
+

@@ -1,0 +1,236 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own code (imported from /root/reference)
+with injected noise.  Runs only in the build container; the GPU box never sees the reference.
+
+    python oracle/make_golden.py            # writes tests/golden/
+
+How noise is injected (the reference's algorithm is not changed):
+  * torch.rand_like(x)            -> next pre-generated U[0,1) tensor of x's shape
+  * torch.multinomial(p, 1)       -> argmax(p / q) with the next pre-generated Exp(1) tensor
+    (bit-identical to what torch.multinomial does internally, SURVEY 8c')
+``.cuda()`` is hard-coded throughout the reference, so Tensor.cuda / Module.cuda are made no-ops.
+
+Inputs and weights are NOT stored: they are regenerated from seeds by dagnet_amd.synthetic in the
+tests (a float64 checksum of each is stored to catch generator drift).  Stored: reference outputs.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+sys.path.insert(0, "/root/reference")
+
+from models.avrnn.model import AVRNN as RefAVRNN            # noqa: E402
+from models.baseline.model import VRNN as RefVRNN            # noqa: E402
+from models.dagnet.model import DAGNet as RefDAGNet          # noqa: E402
+from models.dagnet.gat.gat_model import GAT as RefGAT        # noqa: E402
+from models.dagnet.gcn.gcn_model import GCN as RefGCN        # noqa: E402
+from models.utils import adjacency_matrix as ref_adj         # noqa: E402
+from models.utils import utils as ref_utils                  # noqa: E402
+
+from dagnet_amd import synthetic as syn                       # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+class Injector:
+    """Feeds pre-generated noise to torch.rand_like / torch.multinomial, in call order."""
+
+    def __init__(self):
+        self.eps, self.q = [], []
+        self.margins, self.goals = [], []
+        self._rand_like, self._multinomial = torch.rand_like, torch.multinomial
+
+    def __enter__(self):
+        def rand_like(x, *a, **k):
+            e = self.eps.pop(0)
+            assert e.shape == x.shape, (e.shape, x.shape)
+            return e.clone()
+
+        def multinomial(p, n, *a, **k):
+            assert n == 1
+            q = self.q.pop(0)
+            ratio = p / q
+            top2 = torch.topk(ratio, 2, dim=-1).values
+            self.margins.append(((top2[:, 0] - top2[:, 1]) / top2[:, 0]).clone())
+            idx = torch.argmax(ratio, dim=-1, keepdim=True)
+            self.goals.append(idx[:, 0].clone())
+            return idx
+
+        torch.rand_like, torch.multinomial = rand_like, multinomial
+        return self
+
+    def __exit__(self, *a):
+        torch.rand_like, torch.multinomial = self._rand_like, self._multinomial
+
+
+def checksum(t):
+    return float(np.asarray(t, dtype=np.float64).sum())
+
+
+def build_case(name, kind, args_kw, sizes, obs_len, pred_len, seed, K, data_kind="bsk", g_cells=(9, 10)):
+    args = syn.make_args(obs_len=obs_len, pred_len=pred_len, **args_kw)
+    n_max = int(max(sizes))
+    if kind == "vrnn":
+        ref = RefVRNN(args)
+    elif kind == "avrnn":
+        ref = RefAVRNN(args)
+    else:
+        ref = RefDAGNet(args, n_max)
+    sd = syn.random_state_dict(ref, seed)
+    ref.load_state_dict(sd)
+    ref.eval()
+    batch = syn.make_batch(sizes, obs_len, pred_len, seed, kind=data_kind, g_cells=g_cells)
+    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = batch
+    N = obs.shape[1]
+    Z, G = args.z_dim, args.g_dim
+    eps_f = syn.uniform_noise(seed, "eps_forward", (obs_len - 1, N, Z))
+    eps_s = syn.uniform_noise(seed, "eps_sample", (K, pred_len, N, Z))
+    q_s = syn.exp1_noise(seed, "q_sample", (K, pred_len, N, G)) if kind == "dagnet" else None
+
+    out = {}
+    # ---- teacher-forced pass over the observed steps
+    with torch.no_grad(), Injector() as inj:
+        inj.eps = [eps_f[t] for t in range(obs_len - 1)]
+        if kind == "vrnn":
+            kld, nll, h = ref(obs_rel)
+            ce = torch.zeros(1)
+        elif kind == "avrnn":
+            adj = _ref_obs_adj(args, sse, obs, gt)
+            kld, nll, h = ref(obs_rel, adj)
+            ce = torch.zeros(1)
+        else:
+            adj = _ref_obs_adj(args, sse, obs, gt)
+            goals_ohe = ref_utils.to_goals_one_hot(obs_goals, G)
+            kld, nll, ce, h = ref(obs, obs_rel, goals_ohe, sse, adj)
+        assert not inj.eps
+    out.update(fwd_kld=kld.numpy(), fwd_nll=nll.numpy(), fwd_ce=ce.numpy(), fwd_h=h.numpy())
+    # ---- K rollouts from h
+    samples, goals, margins = [], [], []
+    for k in range(K):
+        with torch.no_grad(), Injector() as inj:
+            inj.eps = [eps_s[k, t] for t in range(pred_len)]
+            if kind == "vrnn":
+                s = ref.sample(pred_len, h)
+            elif kind == "avrnn":
+                s = ref.sample(pred_len, h, obs[-1], sse)
+            else:
+                inj.q = [q_s[k, t] for t in range(pred_len)]
+                s = ref.sample(pred_len, h, obs[-1], goals_ohe[-1], sse)
+                goals.append(torch.stack(inj.goals).numpy())
+                margins.append(torch.stack(inj.margins).numpy())
+            assert not inj.eps and not inj.q
+        samples.append(s.numpy())
+    samples = np.stack(samples)
+    out["samples"] = samples
+    if goals:
+        out["goals"] = np.stack(goals).astype(np.int32)
+        out["margins"] = np.stack(margins).astype(np.float32)
+    # ---- metrics exactly as evaluate() computes them
+    ade, fde = [], []
+    for k in range(K):
+        a = ref_utils.relative_to_abs(torch.from_numpy(samples[k]), obs[-1])
+        ade.append(ref_utils.average_displacement_error(a, gt, mode="raw"))
+        fde.append(ref_utils.final_displacement_error(a[-1], gt[-1], mode="raw"))
+    out["ade_raw"] = torch.stack(ade).numpy()
+    out["fde_raw"] = torch.stack(fde).numpy()
+    out["ade_sum"] = np.float32(_ref_evaluate_helper(ade, sse))
+    out["fde_sum"] = np.float32(_ref_evaluate_helper(fde, sse))
+    meta = dict(name=name, kind=kind, args=args_kw, sizes=[int(s) for s in sizes], obs_len=obs_len, pred_len=pred_len,
+                seed=seed, K=K, data_kind=data_kind, g_cells=list(g_cells), n_max_agents=n_max,
+                checks=dict(obs=checksum(obs), gt=checksum(gt), eps_f=checksum(eps_f), eps_s=checksum(eps_s),
+                            q_s=checksum(q_s) if q_s is not None else 0.0,
+                            weights=float(sum(checksum(v) for k_, v in sd.items() if v.dtype.is_floating_point))))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: N={N} samples{samples.shape} kld={float(kld):.5f} nll={float(nll):.5f} ce={float(ce):.5f} "
+          f"ade_sum={float(out['ade_sum']):.4f}" + (f" min_margin={float(np.min(out['margins'])):.2e}" if goals else ""))
+
+
+def _ref_obs_adj(args, sse, obs, gt):
+    if args.adjacency_type == 0:
+        return ref_adj.compute_adjs(args, sse)
+    if args.adjacency_type == 1:
+        return ref_adj.compute_adjs_distsim(args, sse, obs, gt)
+    return ref_adj.compute_adjs_knnsim(args, sse, obs, gt)
+
+
+def _ref_evaluate_helper(error, sse):
+    # models/dagnet/evaluate_bsk.py:71-82 cannot be imported without running its argparse at import
+    # time on this process's argv; it is 8 lines, re-issued here against the reference's own utils
+    # and cross-checked below against the imported function when the import is possible.
+    err = torch.stack(error, dim=1)
+    tot = 0
+    for (s, e) in sse:
+        tot = tot + torch.min(torch.sum(err[s.item():e.item()], dim=0))
+    return float(tot)
+
+
+def graph_case(name, kind, nin, nhid, nout, sizes, seed, nheads=4, alpha=0.2):
+    ref = RefGAT(nin, nhid, nout, alpha, nheads) if kind == "gat" else RefGCN(nin, nhid, nout)
+    sd = syn.random_state_dict(ref, seed)
+    ref.load_state_dict(sd)
+    ref.eval()
+    n = int(sum(sizes))
+    x = syn.uniform_noise(seed, "graph_x", (n, nin)) * 2 - 1
+    pos = syn.uniform_noise(seed, "graph_pos", (n, 2)) * 10
+    sse = syn.seq_start_end(sizes)
+    outs = {}
+    for at, fn in ((0, lambda: ref_adj.adjs_fully_connected_pred(sse)),
+                   (1, lambda: ref_adj.adjs_distance_sim_pred(1.2, sse, pos)),
+                   (2, lambda: ref_adj.adjs_knn_sim_pred(3, sse, pos))):
+        adj = fn()
+        assert adj.dtype == torch.float32
+        with torch.no_grad():
+            outs[f"adj{at}"] = adj.numpy()
+            outs[f"out{at}"] = ref(x, adj).numpy()
+    meta = dict(name=name, kind=kind, nin=nin, nhid=nhid, nout=nout, sizes=[int(s) for s in sizes], seed=seed,
+                nheads=nheads, alpha=alpha, checks=dict(x=checksum(x), pos=checksum(pos)))
+    outs["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **outs)
+    print(f"{name}: out {outs['out1'].shape}")
+
+
+TINY = dict(h_dim=16, z_dim=8, rnn_dim=16, g_dim=12)
+REAL = dict(h_dim=64, z_dim=32, rnn_dim=64, g_dim=90)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # --- tiny dims, ragged scenes, every graph x adjacency combination
+    for L in (1, 2):
+        build_case(f"vrnn_tiny_L{L}", "vrnn", dict(TINY, n_layers=L), [2, 5, 3], 4, 5, 10 + L, 2)
+    for gm in ("gat", "gcn"):
+        for at in (0, 1, 2):
+            kw = dict(TINY, n_layers=2 if at != 2 else 1, graph_model=gm, adjacency_type=at, top_k_neigh=3 if at == 2 else None)
+            build_case(f"avrnn_tiny_{gm}_adj{at}", "avrnn", kw, [2, 5, 3], 4, 5, 20 + at, 2)
+            build_case(f"dagnet_tiny_{gm}_adj{at}", "dagnet", kw, [2, 5, 3], 4, 5, 30 + at, 2, g_cells=(3, 4), data_kind="sdd")
+    # --- real basketball dims (5 and 10 agents per scene), obs 10 / pred 40
+    build_case("vrnn_bsk", "vrnn", dict(REAL, n_layers=2), [10, 10], 10, 40, 41, 2)
+    build_case("avrnn_bsk_gat", "avrnn", dict(REAL, n_layers=1), [5, 5, 5], 10, 40, 42, 2)
+    build_case("avrnn_bsk_gat_L2_n10", "avrnn", dict(REAL, n_layers=2), [10, 10], 10, 40, 43, 2)
+    build_case("dagnet_bsk_gat_n5", "dagnet", dict(REAL, n_layers=2), [5, 5, 5], 10, 40, 44, 2)
+    build_case("dagnet_bsk_gat_n10", "dagnet", dict(REAL, n_layers=2), [10, 10, 10], 10, 40, 45, 3)
+    build_case("dagnet_bsk_gcn_n10", "dagnet", dict(REAL, n_layers=2, graph_model="gcn"), [10, 10], 10, 40, 46, 2)
+    # --- SDD-shaped: obs 8 / pred 12, ragged, z=16 (shipped A-VRNN/VRNN SDD checkpoints)
+    build_case("avrnn_sdd_gat", "avrnn", dict(REAL, z_dim=16, n_layers=1), [2, 7, 4, 12], 8, 12, 47, 2, data_kind="sdd")
+    build_case("vrnn_sdd", "vrnn", dict(REAL, z_dim=16, n_layers=2), [2, 7, 4], 8, 12, 48, 2, data_kind="sdd")
+    # --- stand-alone graph modules
+    graph_case("gat_hid", "gat", 64, 8, 64, [2, 5, 3, 10], 51)
+    graph_case("gat_goal", "gat", 90, 8, 90, [3, 10], 52)
+    graph_case("gcn_hid", "gcn", 64, 8, 64, [2, 5, 3, 10], 53)
+    graph_case("gat_tiny", "gat", 12, 4, 20, [1, 4, 2], 54, nheads=2)
+
+
+if __name__ == "__main__":
+    main()

@@ -546,7 +546,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
                 smem[L.xabs + m] = R.x0[grow * 2 + 0];
                 smem[L.xabs + M + m] = R.x0[grow * 2 + 1];
             }
-            if (dag) ri_gidx[m] = R.g0[grow];
+            if (dag) ri_gidx[m] = min(max(R.g0[grow], 0), D.G - 1);
         }
     } else if (MODE == MODE_GRAPH) {
         const DnGraph &Gr = R.gwhich == 0 ? W.g_hid : W.g_goal;
@@ -583,8 +583,8 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
                 if (dag) {
                     smem[L.xabs + m] = R.traj[((int64_t)t * R.N + grow) * 2 + 0];
                     smem[L.xabs + M + m] = R.traj[((int64_t)t * R.N + grow) * 2 + 1];
-                    ri_gprev[m] = R.goals[(int64_t)(t - 1) * R.N + grow];
-                    ri_gidx[m] = R.goals[(int64_t)t * R.N + grow];
+                    ri_gprev[m] = min(max(R.goals[(int64_t)(t - 1) * R.N + grow], 0), D.G - 1);
+                    ri_gidx[m] = min(max(R.goals[(int64_t)t * R.N + grow], 0), D.G - 1);
                 }
             }
             if (has_graph) load_adjacency(P, ri, ri_sid, R.adj + (int64_t)t * R.adj_tstride);
@@ -637,7 +637,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
                         const int gi = reinterpret_cast<int *>(smem + L.red)[(nsl + i) * M + m];
                         if (v > best || (v == best && gi < bi)) { best = v; bi = gi; }
                     }
-                    if (R.force_goals) bi = R.force_goals[((int64_t)krow * R.T + t) * NK + grow];
+                    if (R.force_goals) bi = min(max(R.force_goals[((int64_t)krow * R.T + t) * NK + grow], 0), D.G - 1);
                     ri_gidx[m] = bi;
                     if (R.out_goals) R.out_goals[((int64_t)krow * R.T + t) * NK + grow] = bi;
                 }

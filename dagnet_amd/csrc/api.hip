@@ -617,8 +617,16 @@ static int check_plan(const dagnet_model *m, const dagnet_plan *p) {
     return DAGNET_OK;
 }
 
+#ifdef DN_PROFILE
+static long long *g_prof = nullptr;
+extern "C" void dagnet_debug_set_prof(long long *d_prof) { g_prof = d_prof; }
+#endif
+
 static void fill_common(DnParams &P, const dagnet_model *m, const dagnet_plan *p) {
     memset(&P, 0, sizeof(P));
+#ifdef DN_PROFILE
+    P.r.prof = g_prof;
+#endif
     P.d = m->dims;
     P.l = p->lds;
     P.w = m->w;
@@ -630,6 +638,9 @@ static void fill_common(DnParams &P, const dagnet_model *m, const dagnet_plan *p
     P.r.N = p->N;
     P.r.K = p->K;
     P.r.n_tiles = p->n_tiles;
+#ifdef DN_PROFILE
+    P.r.prof = g_prof;
+#endif
 }
 
 extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_h0, const float *d_x0,

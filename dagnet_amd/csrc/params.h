@@ -113,6 +113,7 @@ struct DnRun {
     const float *gx;
     float *gout;
     int32_t gwhich;
+    long long *prof;            // DN_PROFILE builds: per-phase cycle counters of tile 0 (else unused)
 };
 
 struct DnParams {

@@ -49,39 +49,93 @@ struct GemmIn {
     int off[DN_MAX_SEG];
 };
 
-template <class Epi>
-__device__ __forceinline__ void gemm(const DnCtx &P, const DnLin &L, const GemmIn &in, Epi epi) {
+// k-groups of all segments of a layer as one sequence: g -> (weight fragment pointer, LDS offset)
+struct KSeq {
+    const float4 *w[DN_MAX_SEG];
+    int b[DN_MAX_SEG];
+    int c1, c2, total;
+    __device__ __forceinline__ const float4 *wptr(int g) const {
+        return g < c1 ? w[0] + g * 64 : (g < c2 ? w[1] + (g - c1) * 64 : w[2] + (g - c2) * 64);
+    }
+    __device__ __forceinline__ int boff(int g, int M) const {
+        return g < c1 ? b[0] + g * 8 * M : (g < c2 ? b[1] + (g - c1) * 8 * M : b[2] + (g - c2) * 8 * M);
+    }
+};
+
+__device__ __forceinline__ KSeq make_kseq(const float *wp, const DnLin &L, const int *in_off, int nt, int lane) {
+    KSeq q;
+    int cum = 0;
+#pragma unroll
+    for (int s = 0; s < DN_MAX_SEG; ++s) {
+        const bool on = s < L.nseg;
+        const int kg = on ? L.kg[s] : 0;
+        q.w[s] = reinterpret_cast<const float4 *>(wp + (on ? L.w[s] : L.w[0])) + (size_t)nt * kg * 64 + lane;
+        q.b[s] = on ? in_off[s] : 0;
+        cum += kg;
+        if (s == 0) q.c1 = cum;
+        if (s == 1) q.c2 = cum;
+    }
+    q.total = cum;
+    return q;
+}
+
+#define DN_CHG 4  // same for the three weight streams of a GRU layer
+#define DN_CH 8   // k-groups per prefetch chunk: 8 x float4 of weights in flight per accumulator stream
+
+template <class Pre, class Epi>
+__device__ __forceinline__ void gemm(const DnCtx &P, const DnLin &L, const GemmIn &in, Pre pre, Epi epi) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lm = lane & 31, lh = lane >> 5;
     const int M = P.l.M, MT = M >> 5;
     const int npairs = L.nt * MT;
     for (int pair = wave; pair < npairs; pair += DN_WAVES) {
         const int nt = pair / MT, mt = pair - nt * MT;
+        const int m = mt * 32 + lm;
+        const KSeq q = make_kseq(P.r.wp, L, in.off, nt, lane);
+        const int bl = lh * M + m;
+        float4 a0[DN_CH], a1[DN_CH];
+        float add[16];
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        auto loadw = [&](float4(&a)[DN_CH], int c) {
 #pragma unroll
-        for (int s = 0; s < DN_MAX_SEG; ++s) {
-            if (s >= L.nseg) break;
-            const int kg = L.kg[s];
-            const float4 *__restrict__ w4 = reinterpret_cast<const float4 *>(P.r.wp + L.w[s]) + (size_t)nt * kg * 64 + lane;
-            const float *b = smem + in.off[s] + lh * M + mt * 32 + lm;
-#pragma unroll 2
-            for (int g = 0; g < kg; ++g) {
-                const float4 a = w4[g * 64];
-                const float b0 = b[(g * 8 + 0) * M], b1 = b[(g * 8 + 2) * M];
-                const float b2 = b[(g * 8 + 4) * M], b3 = b[(g * 8 + 6) * M];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b3, acc, 0, 0, 0);
+            for (int j = 0; j < DN_CH; ++j) {
+                const int g = min(c * DN_CH + j, q.total - 1);
+                a[j] = *q.wptr(g);
+            }
+        };
+        auto compute = [&](const float4(&a)[DN_CH], int c) {
+#pragma unroll
+            for (int j = 0; j < DN_CH; ++j) {
+                const int g = c * DN_CH + j;
+                if (g < q.total) {
+                    const float *b = smem + q.boff(g, M) + bl;
+                    const float b0 = b[0], b1 = b[2 * M], b2 = b[4 * M], b3 = b[6 * M];
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].x, b0, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].y, b1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].z, b2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j].w, b3, acc, 0, 0, 0);
+                }
+            }
+        };
+        const int nch = (q.total + DN_CH - 1) / DN_CH;
+        loadw(a0, 0);
+        // epilogue addends (bias, one-hot gather) are fetched while the first weights are in flight
+#pragma unroll
+        for (int r = 0; r < 16; ++r) add[r] = pre(nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, m);
+        for (int c = 0; c < nch; c += 2) {
+            if (c + 1 < nch) loadw(a1, c + 1);
+            compute(a0, c);
+            if (c + 1 < nch) {
+                if (c + 2 < nch) loadw(a0, c + 2);
+                compute(a1, c + 1);
             }
         }
-        const int m = mt * 32 + lm;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            epi(f, m, acc[r]);
+            epi(f, m, acc[r] + add[r]);
         }
     }
 }
@@ -93,91 +147,110 @@ __device__ __forceinline__ void linear(const DnCtx &P, const DnLin &L, const Gem
     const float *__restrict__ wp = P.r.wp;
     const int M = P.l.M;
     const int ld = L.nt * 32;
-    gemm(P, L, in, [&](int f, int m, float v) {
-        if (L.bias >= 0) v += wp[L.bias + f];
-        if (L.gather >= 0) v += wp[L.gather + gsel[m] * ld + f];
-        if (ACT == 1) v = lrelu(v, 0.01f);
-        if (ACT == 2) v = fmaxf(v, 0.f);
-        smem[out_off + f * M + m] = v;
-    });
+    gemm(
+        P, L, in,
+        [&](int f, int m) {
+            float v = 0.f;
+            if (L.bias >= 0) v += wp[L.bias + f];
+            if (L.gather >= 0) v += wp[L.gather + gsel[m] * ld + f];
+            return v;
+        },
+        [&](int f, int m, float v) {
+            if (ACT == 1) v = lrelu(v, 0.01f);
+            if (ACT == 2) v = fmaxf(v, 0.f);
+            smem[out_off + f * M + m] = v;
+        });
 }
 
 // Fused GRU layer: 4 accumulators (r, z, n_input, n_hidden) per output tile, gates in the epilogue.
+// k-group sequence = input segments then the hidden segment; the n gate switches accumulator there.
 __device__ __forceinline__ void gru_layer(const DnCtx &P, const DnGru &G, const GemmIn &xin, int nxseg, int h_off, int out_off) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int lm = lane & 31, lh = lane >> 5;
     const int M = P.l.M, MT = M >> 5;
     const float *__restrict__ wp = P.r.wp;
     const int npairs = G.r.nt * MT;
+    int in_off[DN_MAX_SEG];
+#pragma unroll
+    for (int s = 0; s < DN_MAX_SEG; ++s) in_off[s] = s < nxseg ? xin.off[s] : h_off;
     for (int pair = wave; pair < npairs; pair += DN_WAVES) {
         const int nt = pair / MT, mt = pair - nt * MT;
+        const int m = mt * 32 + lm;
+        const int bl = lh * M + m;
+        const KSeq qr = make_kseq(wp, G.r, in_off, nt, lane);
+        const KSeq qz = make_kseq(wp, G.z, in_off, nt, lane);
+        const KSeq qi = make_kseq(wp, G.ni, in_off, nt, lane);       // input part only
+        const int kx = qi.total;                                      // k-groups before the hidden segment
+        const float4 *wh = reinterpret_cast<const float4 *>(wp + G.nh.w[0]) + (size_t)nt * G.nh.kg[0] * 64 + lane;
+        float4 cr0[DN_CHG], cz0[DN_CHG], cn0[DN_CHG], cr1[DN_CHG], cz1[DN_CHG], cn1[DN_CHG];
         f32x16 ar, az, ai, ah;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { ar[r] = 0.f; az[r] = 0.f; ai[r] = 0.f; ah[r] = 0.f; }
+        auto loadw = [&](float4(&cr)[DN_CHG], float4(&cz)[DN_CHG], float4(&cn)[DN_CHG], int c) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            if (s >= nxseg) break;
-            const int kg = G.r.kg[s];
-            const size_t fo = (size_t)nt * kg * 64 + lane;
-            const float4 *__restrict__ wr = reinterpret_cast<const float4 *>(wp + G.r.w[s]) + fo;
-            const float4 *__restrict__ wz = reinterpret_cast<const float4 *>(wp + G.z.w[s]) + fo;
-            const float4 *__restrict__ wn = reinterpret_cast<const float4 *>(wp + G.ni.w[s]) + fo;
-            const float *b = smem + xin.off[s] + lh * M + mt * 32 + lm;
-#pragma unroll 2
-            for (int g = 0; g < kg; ++g) {
-                const float4 cr = wr[g * 64], cz = wz[g * 64], cn = wn[g * 64];
-                const float b0 = b[(g * 8 + 0) * M], b1 = b[(g * 8 + 2) * M];
-                const float b2 = b[(g * 8 + 4) * M], b3 = b[(g * 8 + 6) * M];
-                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr.x, b0, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz.x, b0, az, 0, 0, 0);
-                ai = __builtin_amdgcn_mfma_f32_32x32x2f32(cn.x, b0, ai, 0, 0, 0);
-                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr.y, b1, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz.y, b1, az, 0, 0, 0);
-                ai = __builtin_amdgcn_mfma_f32_32x32x2f32(cn.y, b1, ai, 0, 0, 0);
-                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr.z, b2, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz.z, b2, az, 0, 0, 0);
-                ai = __builtin_amdgcn_mfma_f32_32x32x2f32(cn.z, b2, ai, 0, 0, 0);
-                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr.w, b3, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz.w, b3, az, 0, 0, 0);
-                ai = __builtin_amdgcn_mfma_f32_32x32x2f32(cn.w, b3, ai, 0, 0, 0);
+            for (int j = 0; j < DN_CHG; ++j) {
+                const int g = min(c * DN_CHG + j, qr.total - 1);
+                cr[j] = *qr.wptr(g);
+                cz[j] = *qz.wptr(g);
+                cn[j] = g < kx ? *qi.wptr(g) : wh[(g - kx) * 64];
             }
-        }
-        {
-            const int s = nxseg;   // hidden segment of r and z; nh has a single segment
-            const int kg = G.r.kg[s];
-            const size_t fo = (size_t)nt * kg * 64 + lane;
-            const float4 *__restrict__ wr = reinterpret_cast<const float4 *>(wp + G.r.w[s]) + fo;
-            const float4 *__restrict__ wz = reinterpret_cast<const float4 *>(wp + G.z.w[s]) + fo;
-            const float4 *__restrict__ wn = reinterpret_cast<const float4 *>(wp + G.nh.w[0]) + fo;
-            const float *b = smem + h_off + lh * M + mt * 32 + lm;
-#pragma unroll 2
-            for (int g = 0; g < kg; ++g) {
-                const float4 cr = wr[g * 64], cz = wz[g * 64], cn = wn[g * 64];
-                const float b0 = b[(g * 8 + 0) * M], b1 = b[(g * 8 + 2) * M];
-                const float b2 = b[(g * 8 + 4) * M], b3 = b[(g * 8 + 6) * M];
-                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr.x, b0, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz.x, b0, az, 0, 0, 0);
-                ah = __builtin_amdgcn_mfma_f32_32x32x2f32(cn.x, b0, ah, 0, 0, 0);
-                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr.y, b1, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz.y, b1, az, 0, 0, 0);
-                ah = __builtin_amdgcn_mfma_f32_32x32x2f32(cn.y, b1, ah, 0, 0, 0);
-                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr.z, b2, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz.z, b2, az, 0, 0, 0);
-                ah = __builtin_amdgcn_mfma_f32_32x32x2f32(cn.z, b2, ah, 0, 0, 0);
-                ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr.w, b3, ar, 0, 0, 0);
-                az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz.w, b3, az, 0, 0, 0);
-                ah = __builtin_amdgcn_mfma_f32_32x32x2f32(cn.w, b3, ah, 0, 0, 0);
+        };
+        auto compute = [&](const float4(&cr)[DN_CHG], const float4(&cz)[DN_CHG], const float4(&cn)[DN_CHG], int c) {
+#pragma unroll
+            for (int j = 0; j < DN_CHG; ++j) {
+                const int g = c * DN_CHG + j;
+                if (g < qr.total) {
+                    const float *b = smem + qr.boff(g, M) + bl;
+                    const float b0 = b[0], b1 = b[2 * M], b2 = b[4 * M], b3 = b[6 * M];
+                    ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr[j].x, b0, ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz[j].x, b0, az, 0, 0, 0);
+                    ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr[j].y, b1, ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz[j].y, b1, az, 0, 0, 0);
+                    ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr[j].z, b2, ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz[j].z, b2, az, 0, 0, 0);
+                    ar = __builtin_amdgcn_mfma_f32_32x32x2f32(cr[j].w, b3, ar, 0, 0, 0);
+                    az = __builtin_amdgcn_mfma_f32_32x32x2f32(cz[j].w, b3, az, 0, 0, 0);
+                    if (g < kx) {
+                        ai = __builtin_amdgcn_mfma_f32_32x32x2f32(cn[j].x, b0, ai, 0, 0, 0);
+                        ai = __builtin_amdgcn_mfma_f32_32x32x2f32(cn[j].y, b1, ai, 0, 0, 0);
+                        ai = __builtin_amdgcn_mfma_f32_32x32x2f32(cn[j].z, b2, ai, 0, 0, 0);
+                        ai = __builtin_amdgcn_mfma_f32_32x32x2f32(cn[j].w, b3, ai, 0, 0, 0);
+                    } else {
+                        ah = __builtin_amdgcn_mfma_f32_32x32x2f32(cn[j].x, b0, ah, 0, 0, 0);
+                        ah = __builtin_amdgcn_mfma_f32_32x32x2f32(cn[j].y, b1, ah, 0, 0, 0);
+                        ah = __builtin_amdgcn_mfma_f32_32x32x2f32(cn[j].z, b2, ah, 0, 0, 0);
+                        ah = __builtin_amdgcn_mfma_f32_32x32x2f32(cn[j].w, b3, ah, 0, 0, 0);
+                    }
+                }
             }
-        }
-        const int m = mt * 32 + lm;
+        };
+        const int nch = (qr.total + DN_CHG - 1) / DN_CHG;
+        loadw(cr0, cz0, cn0, 0);
+        float br[16], bz[16], bi[16], bh[16], hold[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int f = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float rg = sigmoidf_(ar[r] + wp[G.r.bias + f]);
-            const float zg = sigmoidf_(az[r] + wp[G.z.bias + f]);
-            const float ng = tanhf((ai[r] + wp[G.ni.bias + f]) + rg * (ah[r] + wp[G.nh.bias + f]));
-            const float hold = smem[h_off + f * M + m];
-            smem[out_off + f * M + m] = (1.0f - zg) * ng + zg * hold;
+            br[r] = wp[G.r.bias + f];
+            bz[r] = wp[G.z.bias + f];
+            bi[r] = wp[G.ni.bias + f];
+            bh[r] = wp[G.nh.bias + f];
+            hold[r] = smem[h_off + f * M + m];
+        }
+        for (int c = 0; c < nch; c += 2) {
+            if (c + 1 < nch) loadw(cr1, cz1, cn1, c + 1);
+            compute(cr0, cz0, cn0, c);
+            if (c + 1 < nch) {
+                if (c + 2 < nch) loadw(cr0, cz0, cn0, c + 2);
+                compute(cr1, cz1, cn1, c + 1);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float rg = sigmoidf_(ar[r] + br[r]);
+            const float zg = sigmoidf_(az[r] + bz[r]);
+            const float ng = tanhf((ai[r] + bi[r]) + rg * (ah[r] + bh[r]));
+            smem[out_off + f * M + m] = (1.0f - zg) * ng + zg * hold[r];
         }
     }
 }
@@ -574,6 +647,19 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
     const int t_begin = MODE == MODE_FORWARD ? 1 : 0;
     double kld_acc = 0.0, nll_acc = 0.0, ce_acc = 0.0;   // thread-private partials (forward)
 
+#ifdef DN_PROFILE
+    long long pstamp = clock64();
+#define PH(i)                                                                     \
+    do {                                                                          \
+        if (R.prof && tile == 0 && tid == 0) {                                    \
+            const long long now_ = clock64();                                     \
+            R.prof[i] += now_ - pstamp;                                           \
+            pstamp = now_;                                                        \
+        }                                                                         \
+    } while (0)
+#else
+#define PH(i)
+#endif
     for (int t = t_begin; t < R.T; ++t) {
         GemmIn in;
         // ------------------------------------------------------------------ inputs of the step
@@ -600,6 +686,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
             }
             if (MODE == MODE_SAMPLE) build_adjacency(P, ri, L.xabs);    // PRE-update positions
             __syncthreads();
+            PH(0);
 
             // -------------------------------------------------------------- goal head
             in.off[0] = L.d; in.off[1] = hl;
@@ -609,7 +696,9 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
             linear<0>(P, W.dec_goal2, in, L.decg, nullptr);
             __syncthreads();
             softmax_rows(P, L.decg, D.G);
+            PH(1);
             graph_apply(P, W.g_goal, ri, L.decg, L.gcomb, L.gg);
+            PH(2);
             in.off[0] = L.decg; in.off[1] = L.gg;
             linear<0>(P, W.lg_goals, in, L.gcomb, nullptr);
             __syncthreads();
@@ -643,6 +732,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
                 }
             }
             __syncthreads();
+            PH(3);
         }
 
         // ------------------------------------------------------------------ encoder (forward)
@@ -672,6 +762,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
         in.off[0] = L.t2;
         linear<0>(P, W.prior_ml, in, L.t1, nullptr);
         __syncthreads();
+        PH(4);
         // ------------------------------------------------------------------ latent sample
         {
             const int zp = (D.Z + 7) & ~7;
@@ -704,6 +795,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
             }
             __syncthreads();
         }
+        PH(5);
         // ------------------------------------------------------------------ phi_z, decoder
         in.off[0] = L.t2;
         linear<1>(P, W.phi_z0, in, L.t1, nullptr);
@@ -721,6 +813,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
         small_linear<0>(P, W.dec_mean, L.t2, L.dm, D.X);
         if (MODE == MODE_FORWARD) small_linear<0>(P, W.dec_logvar, L.t2, L.dm + D.X * M, D.X);
         __syncthreads();
+        PH(6);
         if (MODE == MODE_SAMPLE) {
             if (live)
                 for (int c = sl; c < D.X; c += nsl)
@@ -744,6 +837,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
                 nll_acc += 0.5 * (double)e;
             }
         }
+        PH(7);
         // ------------------------------------------------------------------ GRU
         for (int l = 0; l < D.L; ++l) {
             GemmIn xi;
@@ -755,6 +849,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
             copy_rows(L.h[l], L.t3, W.gru[l].r.nt * 32 * M);
             __syncthreads();
         }
+        PH(8);
         // ------------------------------------------------------------------ graph refinement
         if (MODE == MODE_SAMPLE && avr) {
             // A-VRNN builds the adjacency from the UPDATED positions (models/avrnn/model.py:201-209)
@@ -774,6 +869,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
             copy_rows(hl, L.t2, W.blend.nt * 32 * M);
             __syncthreads();
         }
+        PH(9);
         if (MODE == MODE_SAMPLE && dag) {
             if (sl == 0) {
                 smem[L.xabs + m] += smem[L.dm + m];
@@ -793,7 +889,7 @@ __global__ __launch_bounds__(DN_THREADS, 1) void dagnet_rollout_kernel(const DnS
             }
         // deterministic in-tile reduction of the thread-private loss partials
         __syncthreads();
-        double *red = reinterpret_cast<double *>(smem + L.t1);   // 3*256 doubles = 6 KB <= t1
+        double *red = reinterpret_cast<double *>(smem);           // 3*256 doubles = 6 KB <= total (make_layout)
         red[tid] = kld_acc;
         red[DN_THREADS + tid] = nll_acc;
         red[2 * DN_THREADS + tid] = ce_acc;

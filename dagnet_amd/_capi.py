@@ -37,7 +37,7 @@ class _Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "model", "x_dim", "h_dim", "z_dim", "rnn_dim", "n_layers", "g_dim", "n_max_agents",
         "graph_model", "graph_hid", "n_heads", "adjacency_type", "top_k_neigh")] + [
-        ("sigma", C.c_float), ("alpha", C.c_float)]
+        ("alpha", C.c_float), ("sigma", C.c_double)]
 
 
 class _Tensor(C.Structure):
@@ -74,7 +74,7 @@ def load():
         lib.dagnet_sample.argtypes = [vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
         lib.dagnet_forward.argtypes = [vp, vp, C.c_int32, vp, vp, vp, vp, C.c_int64, vp, C.c_uint64, vp, vp, vp]
         lib.dagnet_graph_forward.argtypes = [vp, vp, C.c_int32, vp, vp, C.c_int64, vp, vp]
-        lib.dagnet_adjacency.argtypes = [vp, C.c_int32, C.c_float, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp]
+        lib.dagnet_adjacency.argtypes = [vp, C.c_int32, C.c_double, C.c_int32, C.c_int32, vp, vp, C.c_int64, vp]
         lib.dagnet_best_of_k.argtypes = [vp, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.dagnet_relative_to_abs.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp]
         lib.dagnet_displacement_errors.argtypes = [C.c_int32, C.c_int32, vp, vp, vp, vp, vp]

@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 #include <math.h>
 #include <algorithm>
 #include <functional>
@@ -14,14 +15,17 @@
 
 #include "../../include/dagnet_hip.h"
 #include "params.h"
+#include "params_v2.h"
 
 extern "C" hipError_t dn_launch_rollout(int mode, const void *d_static, const DnRun *run, size_t lds_bytes, hipStream_t stream);
-extern "C" hipError_t dn_launch_adjacency(int type, float sigma, int top_k, const int32_t *scene_ptr, const int32_t *row_scene,
+extern "C" hipError_t dn_launch_adjacency(int type, double sigma, int top_k, const int32_t *scene_ptr, const int32_t *row_scene,
                                           const int64_t *blk_off, int N, int T, const float *pos, float *out, int64_t ld,
                                           int64_t tstride, hipStream_t st);
 extern "C" hipError_t dn_launch_best_of_k(const int32_t *scene_ptr, int S, int N, int K, int T, const float *rel,
                                           const float *start, const float *gt, float *ade, float *fde, float *scene_best,
                                           double *sums, hipStream_t st);
+extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, const V2Weights *w, const V2Run *r, hipStream_t st);
+extern "C" int dn_v2_has(int model, int n_layers, int z_dim);
 extern "C" hipError_t dn_launch_loss_finalize(int n_tiles, int N, const double *part, double *losses, hipStream_t st);
 extern "C" hipError_t dn_launch_abs_errors(int T, int N, const float *pred, const float *gt, float *ade, float *fde, hipStream_t st);
 extern "C" hipError_t dn_launch_scene_min_sum(const int32_t *scene_ptr, int S, int N, int K, const float *ade, const float *fde,
@@ -54,6 +58,8 @@ struct dagnet_model {
     float *d_wp = nullptr;
     size_t wp_floats = 0;
     int device = 0;
+    bool v2 = false;            // the register-resident kernel (rollout_v2.hip) covers this model
+    V2Weights w2;
 };
 
 struct dagnet_plan {
@@ -65,6 +71,9 @@ struct dagnet_plan {
     void *d_static = nullptr;   // {DnDims, DnLds, DnWeights} prefix of DnParams for this (model, plan)
     int64_t compact_size = 0;
     const dagnet_model *owner = nullptr;
+    // 32-row tiles for the register-resident kernel (only when the model and every scene qualify)
+    int32_t *d_tile2_u0 = nullptr, *d_tile2_nu = nullptr;
+    int n_tiles2 = 0;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -125,6 +134,21 @@ struct Packer {
                         const int n = a * 32 + (l & 31), k = g * 8 + 2 * i + (l >> 5);
                         buf[off + (((size_t)a * kg + g) * 64 + l) * 4 + i] = (n < N && k < K) ? W(n, k) : 0.f;
                     }
+        return off;
+    }
+    // MFMA-chain order (params_v2.h): [nt][kt][j 0..3][lane 64][i 0..3] = W[nt*32+n][kt*32+8j+4h+i]
+    int chain(const WFn &W, int N, int K) {
+        const int nt = (N + 31) / 32, kt = (K + 31) / 32;
+        const int off = align();
+        buf.resize(off + (size_t)nt * kt * 1024, 0.f);
+        for (int a = 0; a < nt; ++a)
+            for (int b = 0; b < kt; ++b)
+                for (int j = 0; j < 4; ++j)
+                    for (int l = 0; l < 64; ++l)
+                        for (int i = 0; i < 4; ++i) {
+                            const int n = a * 32 + (l & 31), k = b * 32 + 8 * j + 4 * (l >> 5) + i;
+                            buf[off + ((((size_t)a * kt + b) * 4 + j) * 64 + l) * 4 + i] = (n < N && k < K) ? W(n, k) : 0.f;
+                        }
         return off;
     }
     int vec(const std::function<float(int)> &f, int n, int npad) {
@@ -330,6 +354,157 @@ DnGru pack_gru(Packer &pk, int l, int R, int H) {
     return g;
 }
 
+// ---- register-resident kernel (rollout_v2.hip): same tensors, MFMA-chain packing -------------
+V2Lin v2_linear(Packer &pk, const std::string &name, int N, int Ktot, std::vector<SegSpec> segs, int gcol0 = -1, int G = 0) {
+    V2Lin L;
+    L.w[0] = L.w[1] = L.w[2] = 0;
+    L.bias = L.gather = -1;
+    const Tensor *W = pk.get(name + ".weight", {N, Ktot});
+    const Tensor *B = pk.get(name + ".bias", {N});
+    if (!W || !B) return L;
+    const float *w = W->p, *b = B->p;
+    for (size_t s = 0; s < segs.size(); ++s) {
+        const int c0 = segs[s].col0;
+        L.w[s] = pk.chain([=](int n, int k) { return w[(size_t)n * Ktot + c0 + k]; }, N, segs[s].K);
+    }
+    L.bias = pk.vec([=](int n) { return b[n]; }, N, pad32(N));
+    if (gcol0 >= 0) L.gather = pk.gather([=](int n, int g) { return w[(size_t)n * Ktot + gcol0 + g]; }, N, G);
+    return L;
+}
+
+V2Lin v2_pair(Packer &pk, const std::string &a, const std::string &b, int Z, int K) {
+    V2Lin L;
+    L.w[0] = L.w[1] = L.w[2] = 0;
+    L.bias = L.gather = -1;
+    const Tensor *Wa = pk.get(a + ".weight", {Z, K}), *Wb = pk.get(b + ".weight", {Z, K});
+    const Tensor *Ba = pk.get(a + ".bias", {Z}), *Bb = pk.get(b + ".bias", {Z});
+    if (!Wa || !Wb || !Ba || !Bb) return L;
+    const float *wa = Wa->p, *wb = Wb->p, *ba = Ba->p, *bb = Bb->p;
+    L.w[0] = pk.chain([=](int n, int k) { return n < Z ? wa[(size_t)n * K + k] : wb[(size_t)(n - Z) * K + k]; }, 2 * Z, K);
+    L.bias = pk.vec([=](int n) { return n < Z ? ba[n] : bb[n - Z]; }, 2 * Z, pad32(2 * Z));
+    return L;
+}
+
+V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, int P) {
+    V2Gat g;
+    memset(&g, 0, sizeof(g));
+    g.nout = nout;
+    std::vector<const float *> Wh(P), ah(P);
+    for (int p = 0; p < P; ++p) {
+        const Tensor *W = pk.get(prefix + ".attention_" + std::to_string(p) + ".W", {nin, F});
+        const Tensor *a = pk.get(prefix + ".attention_" + std::to_string(p) + ".a", {2 * F, 1});
+        if (!W || !a) return g;
+        Wh[p] = W->p;
+        ah[p] = a->p;
+    }
+    const Tensor *Wo = pk.get(prefix + ".out_att.W", {P * F, nout});
+    const Tensor *ao = pk.get(prefix + ".out_att.a", {2 * nout, 1});
+    if (!Wo || !ao) return g;
+    const float *wo = Wo->p, *aop = ao->p;
+    g.heads = pk.chain([=](int n, int k) { return Wh[n / F][(size_t)k * F + (n % F)]; }, P * F, nin);
+    // a . (x W) == x . (W a): the attention logits' two dot products become 2P extra output features
+    g.fold = pk.chain(
+        [=](int q, int k) {
+            const int p = q % P, half = q / P;
+            double acc = 0.0;
+            for (int f = 0; f < F; ++f) acc += (double)Wh[p][(size_t)k * F + f] * (double)ah[p][half * F + f];
+            return (float)acc;
+        },
+        2 * P, nin);
+    g.out = pk.chain([=](int n, int k) { return wo[(size_t)k * nout + n]; }, nout, P * F);
+    g.fold_out = pk.chain(
+        [=](int q, int k) {
+            double acc = 0.0;
+            for (int n = 0; n < nout; ++n) acc += (double)wo[(size_t)k * nout + n] * (double)aop[q * nout + n];
+            return (float)acc;
+        },
+        2, P * F);
+    const Tensor *ga = pk.get(prefix + ".bn1.weight", {nout}), *be = pk.get(prefix + ".bn1.bias", {nout});
+    const Tensor *mu = pk.get(prefix + ".bn1.running_mean", {nout}), *var = pk.get(prefix + ".bn1.running_var", {nout});
+    if (!ga || !be || !mu || !var) return g;
+    const float *gp = ga->p, *bp = be->p, *mp = mu->p, *vp = var->p;
+    const int ld = pad32(nout);
+    g.bn = pk.vec(
+        [=](int i) {
+            const int c = i % ld, row = i / ld;
+            if (c >= nout) return row == 3 ? 1.0f : 0.0f;
+            return row == 0 ? gp[c] : row == 1 ? bp[c] : row == 2 ? mp[c] : sqrtf(vp[c] + 1e-5f);
+        },
+        4 * ld, 4 * ld);
+    return g;
+}
+
+V2Gru v2_gru(Packer &pk, int l, int R, int H) {
+    V2Gru g;
+    memset(&g, 0, sizeof(g));
+    const int Kin = l == 0 ? 2 * H : R;
+    const std::string sl = std::to_string(l);
+    const Tensor *Wi = pk.get("rnn.weight_ih_l" + sl, {3 * R, Kin});
+    const Tensor *Wh = pk.get("rnn.weight_hh_l" + sl, {3 * R, R});
+    const Tensor *Bi = pk.get("rnn.bias_ih_l" + sl, {3 * R});
+    const Tensor *Bh = pk.get("rnn.bias_hh_l" + sl, {3 * R});
+    if (!Wi || !Wh || !Bi || !Bh) return g;
+    const float *wi = Wi->p, *wh = Wh->p, *bi = Bi->p, *bh = Bh->p;
+    auto mk = [&](V2Lin &L, int gate, bool with_x, bool with_h) {
+        L.w[0] = L.w[1] = L.w[2] = 0;
+        L.gather = -1;
+        int s = 0;
+        if (with_x) L.w[s++] = pk.chain([=](int n, int k) { return wi[(size_t)(gate * R + n) * Kin + k]; }, R, Kin);
+        if (with_h) L.w[s++] = pk.chain([=](int n, int k) { return wh[(size_t)(gate * R + n) * R + k]; }, R, R);
+        L.bias = pk.vec([=](int n) { return (with_x ? bi[gate * R + n] : 0.f) + (with_h ? bh[gate * R + n] : 0.f); }, R, pad32(R));
+    };
+    mk(g.r, 0, true, true);
+    mk(g.z, 1, true, true);
+    mk(g.ni, 2, true, false);
+    mk(g.nh, 2, false, true);
+    return g;
+}
+
+bool v2_eligible(const dagnet_config &c) {
+    if (c.model < 0 || c.model > 2) return false;
+    if (c.x_dim != 2 || c.h_dim != 64 || c.rnn_dim != 64) return false;
+    if (!dn_v2_has(c.model, c.n_layers, c.z_dim)) return false;
+    if (c.model != DAGNET_MODEL_VRNN) {
+        if (c.graph_model != DAGNET_GRAPH_GAT || c.n_heads != 4 || c.graph_hid != 8) return false;
+        if (c.adjacency_type != 0 && c.adjacency_type != 1) return false;
+    }
+    if (c.model == DAGNET_MODEL_DAGNET && (c.g_dim > 96 || c.n_max_agents > 16)) return false;
+    return true;
+}
+
+void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W) {
+    memset(&W, 0, sizeof(W));
+    const int H = 64, R = 64, Z = c.z_dim, G = c.g_dim, Dd = 2 * c.n_max_agents;
+    const bool dag = c.model == DAGNET_MODEL_DAGNET, graph = c.model != DAGNET_MODEL_VRNN;
+    DnRaw px0 = pack_raw_linear(pk, "phi_x.0", H, 2), dm = pack_raw_linear(pk, "dec_mean", 2, H);
+    W.phi_x0_w = px0.w; W.phi_x0_b = px0.b;
+    W.dec_mean_w = dm.w; W.dec_mean_b = dm.b;
+    W.phi_x2 = v2_linear(pk, "phi_x.2", H, H, {{0, H}});
+    W.phi_z0 = v2_linear(pk, "phi_z.0", H, Z, {{0, Z}});
+    W.phi_z2 = v2_linear(pk, "phi_z.2", H, H, {{0, H}});
+    if (dag) {
+        W.prior0 = v2_linear(pk, "prior.0", H, G + R, {{G, R}}, 0, G);
+        W.dec0 = v2_linear(pk, "dec.0", H, Dd + G + H + R, {{0, Dd}, {Dd + G, H}, {Dd + G + H, R}}, Dd, G);
+    } else {
+        W.prior0 = v2_linear(pk, "prior.0", H, R, {{0, R}});
+        W.dec0 = v2_linear(pk, "dec.0", H, H + R, {{0, H}, {H, R}});
+    }
+    W.prior2 = v2_linear(pk, "prior.2", H, H, {{0, H}});
+    W.prior_ml = v2_pair(pk, "prior_mean", "prior_logvar", Z, H);
+    W.dec2 = v2_linear(pk, "dec.2", H, H, {{0, H}});
+    for (int l = 0; l < c.n_layers; ++l) W.gru[l] = v2_gru(pk, l, R, H);
+    if (graph) {
+        W.g_hid = v2_gat(pk, dag ? "graph_hiddens" : "graph", R, R, c.graph_hid, c.n_heads);
+        W.blend = v2_linear(pk, dag ? "lg_hiddens" : "lg", R, 2 * R, {{0, R}, {R, R}});
+    }
+    if (dag) {
+        W.dec_goal0 = v2_linear(pk, "dec_goal.0", H, Dd + R + G, {{0, Dd}, {Dd, R}}, Dd + R, G);
+        W.dec_goal2 = v2_linear(pk, "dec_goal.2", G, H, {{0, H}});
+        W.g_goal = v2_gat(pk, "graph_goals", G, G, c.graph_hid, c.n_heads);
+        W.lg_goals = v2_linear(pk, "lg_goals.0", G, 2 * G, {{0, G}, {G, G}});
+    }
+}
+
 }   // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -424,6 +599,8 @@ extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor
         W.lg_goals = pack_linear(pk, "lg_goals.0", G, 2 * G, {{0, G}, {G, G}});
     }
     }
+    m->v2 = v2_eligible(c);
+    if (m->v2 && pk.missing.empty()) v2_pack(pk, c, m->w2);
     if (!pk.missing.empty()) {
         const int rc = fail(DAGNET_ERR_MISSING, "state dict entry missing or mis-shaped: %s", pk.missing.c_str());
         delete m;
@@ -556,6 +733,23 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
         nu.push_back(cnt);
         u += cnt;
     }
+    std::vector<int32_t> u2, nu2;
+    if (m && m->v2 && nmax <= 32) {
+        int64_t v = 0;
+        while (v < units) {
+            int rows = 0, cnt = 0;
+            while (v + cnt < units) {
+                const int s = (int)((v + cnt) % S);
+                const int n = h_scene_ptr[s + 1] - h_scene_ptr[s];
+                if (rows + n > 32) break;
+                rows += n;
+                ++cnt;
+            }
+            u2.push_back((int32_t)v);
+            nu2.push_back(cnt);
+            v += cnt;
+        }
+    }
     dagnet_plan *p = new dagnet_plan();
     p->S = S; p->N = N; p->K = K; p->M = M; p->AS = nmax; p->lds = L;
     p->owner = m;
@@ -568,6 +762,11 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
         if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
     };
     up(reinterpret_cast<void **>(&p->d_scene_ptr), h_scene_ptr, sizeof(int32_t) * (S + 1));
+    p->n_tiles2 = (int)u2.size();
+    if (!u2.empty()) {
+        up(reinterpret_cast<void **>(&p->d_tile2_u0), u2.data(), sizeof(int32_t) * u2.size());
+        up(reinterpret_cast<void **>(&p->d_tile2_nu), nu2.data(), sizeof(int32_t) * nu2.size());
+    }
     if (m) {
         up(reinterpret_cast<void **>(&p->d_tile_u0), u0.data(), sizeof(int32_t) * u0.size());
         up(reinterpret_cast<void **>(&p->d_tile_nu), nu.data(), sizeof(int32_t) * nu.size());
@@ -594,7 +793,7 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
 
 extern "C" void dagnet_plan_destroy(dagnet_plan *p) {
     if (!p) return;
-    void *ptrs[] = {p->d_scene_ptr, p->d_tile_u0, p->d_tile_nu, p->d_row_scene, p->d_off_dense, p->d_off_compact, p->d_loss_part, p->d_static};
+    void *ptrs[] = {p->d_scene_ptr, p->d_tile_u0, p->d_tile_nu, p->d_row_scene, p->d_off_dense, p->d_off_compact, p->d_loss_part, p->d_static, p->d_tile2_u0, p->d_tile2_nu};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -654,6 +853,22 @@ extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_
     if (m->dims.model == DAGNET_MODEL_DAGNET && 2 * p->AS > m->dims.D) return fail(DAGNET_ERR_INVALID, "plan was made for another model");
     if (T == 0) return DAGNET_OK;
     if (int rc = check_plan(m, p)) return rc;
+    if (m->v2 && p->n_tiles2 > 0 && !getenv("DAGNET_FORCE_GENERIC")) {
+        V2Run r;
+        memset(&r, 0, sizeof(r));
+        r.wp = m->d_wp;
+        r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
+        r.S = p->S; r.N = p->N; r.K = p->K; r.T = T; r.n_tiles = p->n_tiles2;
+        r.G = m->dims.G; r.D = m->dims.D; r.adj_type = m->dims.adj_type;
+        r.alpha = m->dims.alpha; r.sigma = m->dims.sigma;
+        r.h0 = d_h0; r.x0 = d_x0; r.g0 = d_g0; r.eps = d_eps; r.q = d_q; r.force_goals = d_force_goals;
+        r.seed = seed; r.out = d_out; r.out_goals = d_out_goals;
+#ifdef DN_PROFILE
+        r.dbg = reinterpret_cast<float *>(g_prof);
+#endif
+        HIP_TRY(dn_launch_rollout_v2(m->dims.model, m->dims.L, m->dims.Z, &m->w2, &r, static_cast<hipStream_t>(stream)));
+        return DAGNET_OK;
+    }
     DnParams P;
     fill_common(P, m, p);
     P.r.T = T;
@@ -721,7 +936,7 @@ extern "C" int dagnet_graph_forward(const dagnet_model *m, const dagnet_plan *p,
     return DAGNET_OK;
 }
 
-extern "C" int dagnet_adjacency(const dagnet_plan *p, int32_t adjacency_type, float sigma, int32_t top_k, int32_t T, const float *d_pos,
+extern "C" int dagnet_adjacency(const dagnet_plan *p, int32_t adjacency_type, double sigma, int32_t top_k, int32_t T, const float *d_pos,
                                 float *d_out, int64_t dense_ld, void *stream) {
     if (!p || !d_out) return fail(DAGNET_ERR_INVALID, "null argument");
     if (adjacency_type < 0 || adjacency_type > 2) return fail(DAGNET_ERR_INVALID, "adjacency_type must be 0,1,2");

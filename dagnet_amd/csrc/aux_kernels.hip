@@ -8,7 +8,7 @@
 #include "rng.h"
 
 // one thread per (t, row): writes the row's adjacency to all members of its scene
-__global__ void dn_adjacency_kernel(int type, float sigma, int top_k, const int32_t *__restrict__ scene_ptr,
+__global__ void dn_adjacency_kernel(int type, double sigma, int top_k, const int32_t *__restrict__ scene_ptr,
                                     const int32_t *__restrict__ row_scene, const int64_t *__restrict__ blk_off,
                                     int N, int T, const float *__restrict__ pos, float *__restrict__ out,
                                     int64_t ld, int64_t tstride) {
@@ -28,7 +28,7 @@ __global__ void dn_adjacency_kernel(int type, float sigma, int top_k, const int3
     if (type == 1) {
         for (int j = 0; j < n; ++j) {
             const double dx = xi - (double)p[(b + j) * 2], dy = yi - (double)p[(b + j) * 2 + 1];
-            o[j] = (float)exp(-sqrt(dx * dx + dy * dy) / (double)sigma);
+            o[j] = (float)exp(-sqrt(dx * dx + dy * dy) / sigma);
         }
     } else {
         const int k = top_k < n ? top_k : n;
@@ -189,7 +189,7 @@ extern "C" hipError_t dn_launch_categorical(int N, int G, const float *w, const 
     return hipGetLastError();
 }
 
-extern "C" hipError_t dn_launch_adjacency(int type, float sigma, int top_k, const int32_t *scene_ptr, const int32_t *row_scene,
+extern "C" hipError_t dn_launch_adjacency(int type, double sigma, int top_k, const int32_t *scene_ptr, const int32_t *row_scene,
                                           const int64_t *blk_off, int N, int T, const float *pos, float *out, int64_t ld,
                                           int64_t tstride, hipStream_t st) {
     const int64_t total = (int64_t)N * T;

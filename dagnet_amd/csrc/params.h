@@ -66,7 +66,8 @@ struct DnWeights {
 struct DnDims {
     int32_t model, graph, adj_type, knn_k;
     int32_t X, H, Z, G, R, L, F, P, D;
-    float sigma, alpha;
+    float alpha;
+    double sigma;
 };
 
 // LDS layout (float offsets); row stride of every [feature][row] buffer is M.

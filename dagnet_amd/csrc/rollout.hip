@@ -471,7 +471,7 @@ __device__ __forceinline__ void build_adjacency(const DnCtx &P, const RowInfo &r
     } else {
         const double xi = (double)smem[pos_off + m], yi = (double)smem[pos_off + M + m];
         if (type == 1) {
-            const double sigma = (double)P.d.sigma;
+            const double sigma = P.d.sigma;
             for (int jl = sl; jl < n; jl += nsl) {
                 const double dx = xi - (double)smem[pos_off + s0 + jl], dy = yi - (double)smem[pos_off + M + s0 + jl];
                 const double d = sqrt(dx * dx + dy * dy);

@@ -1,0 +1,630 @@
+// Register-resident rollout kernel for the standard DAG-Net / A-VRNN / VRNN shapes
+// (x_dim 2, h_dim = rnn_dim = 64, z_dim 16|32, n_layers 1|2, GAT with n_heads*graph_hid = 32,
+// g_dim <= 96, scenes of <= 32 agents, adjacency type 0|1).  Anything else runs on the generic
+// LDS-tiled kernel in rollout.hip.
+//
+// One WAVE owns a tile of <= 32 rows made of whole scene-samples and keeps their entire state
+// in registers for all T steps; there is no workgroup barrier and no activation traffic at all:
+//   * an activation tile is 32 features x 32 rows in the accumulator layout of
+//     v_mfma_f32_32x32x2_f32 ("S": lane = row, register r = feature (r&3)+8(r>>2)+4(lane>>5)),
+//     which is exactly the B operand the next layer's MFMA needs, so dense layers chain
+//     accumulator -> operand with weights streamed from L2 in a matching packed order;
+//   * swapping the operands of the same MFMA gives the product transposed ("T": lane = feature,
+//     register = row), which is the A operand of the per-scene attention aggregation
+//     out^T = Wh^T . alpha^T, so graph attention runs on the matrix cores too and its softmax
+//     weights are built per lane (each lane owns one row of alpha);
+//   * softmax / categorical draw / GRU gates / reparameterisation are per-lane VALU epilogues.
+// Per-wave LDS (a few hundred bytes) is only used to broadcast positions and attention logits.
+//
+// Reference behaviour: models/dagnet/model.py:196-270, models/avrnn/model.py:163-215,
+// models/baseline/model.py:135-170, models/dagnet/gat/gat_layers.py:25-40, gat_model.py:18-22,
+// models/utils/adjacency_matrix.py:21-28,49-58, models/utils/utils.py:200-207.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "params_v2.h"
+#include "rng.h"
+
+typedef float T16 __attribute__((ext_vector_type(16)));
+
+#define FR(r) (((r) & 3) + 8 * ((r) >> 2))
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// raw buffer loads declared straight on the LLVM intrinsics: clang 22's
+// __builtin_amdgcn_raw_buffer_load_b128 collapses to a single dword here (all four lanes of the
+// result alias element 0), these forms select buffer_load_dwordx4 / _dword as expected.
+__device__ f32x4 dn_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float dn_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+
+namespace v2 {
+
+// All weight traffic goes through ONE buffer descriptor (4 SGPRs): per-lane part of the address is a
+// single VGPR (voff, bytes), the per-use part a scalar offset.  With plain pointers the compiler
+// hoists ~150 loop-invariant 64-bit per-lane addresses out of the time loop and spills them.
+struct WBuf {
+    i32x4 rs;
+    __device__ __forceinline__ void init(const float *p) {
+        union { const float *p; int w[2]; } u;
+        u.p = p;
+        rs = i32x4{u.w[0], u.w[1], 0x7fffffff, 0x00020000};
+    }
+    __device__ __forceinline__ float4 ld4(int voff_bytes, int soff_floats) const {
+        asm volatile("" : "+s"(soff_floats));     // keep scalar offsets out of loop-invariant hoisting (SGPR spills)
+        const f32x4 v = dn_buffer_load_f32x4(rs, voff_bytes, soff_floats * 4, 0);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    __device__ __forceinline__ float ld1(int voff_bytes, int soff_floats) const {
+        return dn_buffer_load_f32(rs, voff_bytes, soff_floats * 4, 0);
+    }
+};
+
+__device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
+__device__ __forceinline__ int xhalf(int v) { return __shfl_xor(v, 32); }
+
+template <int N>
+__device__ __forceinline__ void zero(T16 (&x)[N]) {
+#pragma unroll
+    for (int t = 0; t < N; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
+}
+
+// One (n-tile, k-tile) block of packed weights: 4 x float4 per lane = the A (or B) operands of 16 MFMAs.
+struct WBlk {
+    float4 v[4];
+};
+__device__ __forceinline__ WBlk wload(const WBuf &wp, int off, int lane) {
+    WBlk b;
+    asm volatile("" : "+s"(off));     // keep the scalar offset out of loop-invariant hoisting (SGPR spills)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b.v[j] = wp.ld4(lane * 16 + j * 1024, off);
+    return b;
+}
+
+// out[nt] += W(nt,kt) . x[kt]     TR = false: S <- S (weights are the A operand)
+//                                 TR = true : T <- S (weights are the B operand: out = x^T W^T)
+// Weight blocks are software pipelined two deep across the whole step: `pre` is this call's first
+// block (already in flight, issued by the previous call), `next_off` the first block of whatever
+// consumes weights next; the return value is that block, in flight.
+template <int NT, int KT, bool TR>
+__device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, const T16 (&x)[KT], int lane, WBlk pre,
+                                   int next_off) {
+    constexpr int NB = NT * KT;
+    WBlk q0 = pre, q1, q2;
+    q1 = wload(wp, NB > 1 ? off + 1024 : next_off, lane);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        if (b + 2 <= NB) q2 = wload(wp, b + 2 < NB ? off + (b + 2) * 1024 : next_off, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        const int nt = b / KT, kt = b % KT;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 a = q0.v[j];
+            if (!TR) {
+                out[nt] = MFMA(a.x, x[kt][4 * j + 0], out[nt]);
+                out[nt] = MFMA(a.y, x[kt][4 * j + 1], out[nt]);
+                out[nt] = MFMA(a.z, x[kt][4 * j + 2], out[nt]);
+                out[nt] = MFMA(a.w, x[kt][4 * j + 3], out[nt]);
+            } else {
+                out[nt] = MFMA(x[kt][4 * j + 0], a.x, out[nt]);
+                out[nt] = MFMA(x[kt][4 * j + 1], a.y, out[nt]);
+                out[nt] = MFMA(x[kt][4 * j + 2], a.z, out[nt]);
+                out[nt] = MFMA(x[kt][4 * j + 3], a.w, out[nt]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        q0 = q1;
+        q1 = q2;
+    }
+    return q0;
+}
+
+// x[nt][r] += v[nt*32 + feature(r, h)]   for a vector stored [NT*32]
+template <int NT>
+__device__ __forceinline__ void add_vec(T16 (&x)[NT], const WBuf &wp, int off, int voff, int lh) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 b = wp.ld4(voff + lh * 16, off + nt * 32 + 8 * a);
+            x[nt][4 * a + 0] += b.x;
+            x[nt][4 * a + 1] += b.y;
+            x[nt][4 * a + 2] += b.z;
+            x[nt][4 * a + 3] += b.w;
+        }
+}
+
+// ACT: 0 none, 1 LeakyReLU(0.01), 2 ReLU
+template <int ACT, int NT>
+__device__ __forceinline__ void finish(T16 (&x)[NT], const WBuf &wp, const V2Lin &L, int gsel, int lh) {
+    if (L.bias >= 0) add_vec<NT>(x, wp, L.bias, 0, lh);
+    if (L.gather >= 0) add_vec<NT>(x, wp, L.gather, gsel * (NT * 32 * 4), lh);
+    if (ACT != 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[nt][r] = ACT == 1 ? lrelu(x[nt][r], 0.01f) : fmaxf(x[nt][r], 0.f);
+    }
+}
+
+// softmax over the first G features of an S-layout row (features >= G are set to 0)
+template <int NT>
+__device__ __forceinline__ void softmax_feat(T16 (&x)[NT], int G, int lh) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (nt * 32 + FR(r) + 4 * lh < G) mx = fmaxf(mx, x[nt][r]);
+    mx = fmaxf(mx, xhalf(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = (nt * 32 + FR(r) + 4 * lh < G) ? expf(x[nt][r] - mx) : 0.f;
+            x[nt][r] = e;
+            sum += e;
+        }
+    sum += xhalf(sum);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x[nt][r] = x[nt][r] / sum;
+}
+
+// attention weights of this lane's row over the 16 tile rows its half owns:
+// alpha[r] = softmax_j( mask ? LeakyReLU(s1 + s2[j]) : -9e15 ),  j = FR(r) + 4*lh
+__device__ __forceinline__ void attn_weights(T16 &alpha, float s1, const float (&s2)[16], unsigned amask, float slope) {
+    float e[16];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        e[r] = ((amask >> r) & 1u) ? lrelu(s1 + s2[r], slope) : -9e15f;
+        mx = fmaxf(mx, e[r]);
+    }
+    mx = fmaxf(mx, xhalf(mx));
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        e[r] = expf(e[r] - mx);
+        sum += e[r];
+    }
+    sum += xhalf(sum);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) alpha[r] = e[r] / sum;
+}
+
+// Dense GAT (P heads of F features with P*F = 32 -> out_att -> BatchNorm(eval) -> tanh) on the tile.
+// x: KT input tiles (S).  out: NT tiles (S).  xch: per-wave LDS scratch of >= 32*4 floats.
+template <int KT, int NT>
+__device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WBuf &wp, const V2Gat &Gw, unsigned amask,
+                                    float slope, float *xch, int lane, WBlk pre, int next_off) {
+    const int lh = lane >> 5, lc = lane & 31;
+    // Wh for all heads, transposed: lane = head feature, register = tile row
+    T16 whT[1], sf[1];
+    zero(whT);
+    zero(sf);
+    pre = mm<1, KT, true>(whT, wp, Gw.heads, x, lane, pre, Gw.fold);
+    // s1[p] = a_src[p].Wh_row, s2[p] = a_dst[p].Wh_row through folded weights: features 0..3 / 4..7
+    pre = mm<1, KT, false>(sf, wp, Gw.fold, x, lane, pre, Gw.out);
+    float s1[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) s1[p] = __shfl(sf[0][p], lc);          // half 0 holds features 0..3
+    __syncthreads();
+    if (lh == 1) *reinterpret_cast<float4 *>(xch + lc * 4) = make_float4(sf[0][0], sf[0][1], sf[0][2], sf[0][3]);   // features 4..7
+    __syncthreads();
+    float4 s2j[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s2j[r] = *reinterpret_cast<const float4 *>(xch + (FR(r) + 4 * lh) * 4);
+    T16 x2[1];
+    zero(x2);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        float s2[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s2[r] = p == 0 ? s2j[r].x : p == 1 ? s2j[r].y : p == 2 ? s2j[r].z : s2j[r].w;
+        T16 alpha;
+        attn_weights(alpha, s1[p], s2, amask, slope);
+        const bool mine = (lc >> 3) == p;     // this lane's feature belongs to head p
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x2[0] = MFMA(mine ? whT[0][r] : 0.f, alpha[r], x2[0]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x2[0][r] = x2[0][r] > 0.f ? x2[0][r] : expm1f(x2[0][r]);     // ELU
+    // out_att
+    T16 wh2T[NT], sf2[1];
+    zero(wh2T);
+    zero(sf2);
+    pre = mm<NT, 1, true>(wh2T, wp, Gw.out, x2, lane, pre, Gw.fold_out);
+    pre = mm<1, 1, false>(sf2, wp, Gw.fold_out, x2, lane, pre, next_off);
+    const float t1 = __shfl(sf2[0][0], lc), t2own = __shfl(sf2[0][1], lc);
+    __syncthreads();
+    if (lh == 0) xch[lc] = t2own;
+    __syncthreads();
+    float s2o[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s2o[r] = xch[FR(r) + 4 * lh];
+    T16 alpha;
+    attn_weights(alpha, t1, s2o, amask, slope);
+    zero(out);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[nt][r], alpha[r], out[nt]);
+    // BatchNorm1d (running statistics) + tanh; padded features stay 0
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int f0 = nt * 32 + 8 * a + 4 * lh, fs = nt * 32 + 8 * a;
+            const float4 ga = wp.ld4(lh * 16, Gw.bn + fs);
+            const float4 be = wp.ld4(lh * 16, Gw.bn + NT * 32 + fs);
+            const float4 mu = wp.ld4(lh * 16, Gw.bn + 2 * NT * 32 + fs);
+            const float4 sd = wp.ld4(lh * 16, Gw.bn + 3 * NT * 32 + fs);
+            const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
+            const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, s4[4] = {sd.x, sd.y, sd.z, sd.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v = (out[nt][4 * a + i] - m4[i]) / s4[i] * g4[i] + b4[i];
+                out[nt][4 * a + i] = (f0 + i < Gw.nout) ? tanhf(v) : 0.f;
+            }
+        }
+    return pre;
+}
+
+// One GRU layer.  xin: KX input tiles; h: 2 tiles (R = 64), updated in place.
+template <int KX>
+__device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBuf &wp, const V2Gru &Gw, int lane, WBlk pre,
+                                    int next_off) {
+    const int lh = lane >> 5;
+    T16 hn[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        T16 ar[1], az[1], ai[1], ah[1];
+        zero(ar); zero(az); zero(ai); zero(ah);
+        // weights of a gate are packed per output tile: offset of tile nt = nt * (KT*4*64*4) floats
+        const int ox = nt * KX * 1024, oh = nt * 2 * 1024;
+        pre = mm<1, KX, false>(ar, wp, Gw.r.w[0] + ox, xin, lane, pre, Gw.z.w[0] + ox);
+        pre = mm<1, KX, false>(az, wp, Gw.z.w[0] + ox, xin, lane, pre, Gw.ni.w[0] + ox);
+        pre = mm<1, KX, false>(ai, wp, Gw.ni.w[0] + ox, xin, lane, pre, Gw.r.w[1] + oh);
+        pre = mm<1, 2, false>(ar, wp, Gw.r.w[1] + oh, h, lane, pre, Gw.z.w[1] + oh);
+        pre = mm<1, 2, false>(az, wp, Gw.z.w[1] + oh, h, lane, pre, Gw.nh.w[0] + oh);
+        pre = mm<1, 2, false>(ah, wp, Gw.nh.w[0] + oh, h, lane, pre, nt == 0 ? Gw.r.w[0] + KX * 1024 : next_off);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int fs = nt * 32 + 8 * a;
+            const float4 br = wp.ld4(lh * 16, Gw.r.bias + fs);
+            const float4 bz = wp.ld4(lh * 16, Gw.z.bias + fs);
+            const float4 bi = wp.ld4(lh * 16, Gw.ni.bias + fs);
+            const float4 bh = wp.ld4(lh * 16, Gw.nh.bias + fs);
+            const float r4[4] = {br.x, br.y, br.z, br.w}, z4[4] = {bz.x, bz.y, bz.z, bz.w};
+            const float i4[4] = {bi.x, bi.y, bi.z, bi.w}, h4[4] = {bh.x, bh.y, bh.z, bh.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * a + i;
+                const float rg = sigm(ar[0][r] + r4[i]);
+                const float zg = sigm(az[0][r] + z4[i]);
+                const float ng = tanhf((ai[0][r] + i4[i]) + rg * (ah[0][r] + h4[i]));
+                hn[nt][r] = (1.0f - zg) * ng + zg * h[nt][r];
+            }
+        }
+    }
+    h[0] = hn[0];
+    h[1] = hn[1];
+    return pre;
+}
+
+// MODEL: 0 VRNN, 1 A-VRNN, 2 DAG-Net.  NL: GRU layers.  ZT: 32 -> z_dim 32, 16 -> z_dim 16.
+template <int MODEL, int NL, int ZD>
+__global__ __launch_bounds__(64) void rollout_v2_kernel(const V2Weights W, const V2Run R) {
+    __shared__ float xch[32 * 4 + 64];
+    float *pos = xch + 128;                 // [32][2] current absolute positions of the tile rows
+    const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
+    WBuf wp;
+    wp.init(R.wp);
+    constexpr bool DAG = MODEL == 2, GRAPH = MODEL != 0;
+    constexpr int GT = 3;                   // goal tiles (g_dim <= 96)
+
+    // ---- which rows does this wave own?  (uniform scalar walk over the tile's scene-samples)
+    int s0 = lc, n = 1, grow = -1, krow = 0;      // padding lanes: a one-agent scene of their own, never written
+    {
+        const int u0 = R.tile_u0[blockIdx.x], nu = R.tile_nu[blockIdx.x];
+        int row = 0;
+        for (int i = 0; i < nu; ++i) {
+            const int u = u0 + i;
+            const int k = u / R.S, s = u - k * R.S;
+            const int b = R.scene_ptr[s], cnt = R.scene_ptr[s + 1] - b;
+            if (lc >= row && lc < row + cnt) { s0 = row; n = cnt; grow = b + (lc - row); krow = k; }
+            row += cnt;
+        }
+    }
+    const bool live = grow >= 0;
+    const int64_t NK = R.N;
+    const uint32_t rngrow = (uint32_t)(krow * R.N + (live ? grow : 0));
+
+    // ---- state
+    T16 h[NL][2];
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) v = *reinterpret_cast<const float4 *>(R.h0 + ((int64_t)l * R.N + grow) * 64 + nt * 32 + 8 * a + 4 * lh);
+                h[l][nt][4 * a + 0] = v.x; h[l][nt][4 * a + 1] = v.y; h[l][nt][4 * a + 2] = v.z; h[l][nt][4 * a + 3] = v.w;
+            }
+    float xa = 0.f, ya = 0.f;
+    int gi = 0;
+    if (GRAPH && live) { xa = R.x0[grow * 2]; ya = R.x0[grow * 2 + 1]; }
+    if (DAG && live) gi = min(max(R.g0[grow], 0), R.G - 1);
+    unsigned amask = 0;
+
+    auto build_mask = [&]() {
+        // rows j = FR(r)+4*lh of the tile that are in this row's scene and have adjacency > 0
+        __syncthreads();
+        if (lh == 0) { pos[lc * 2] = xa; pos[lc * 2 + 1] = ya; }
+        __syncthreads();
+        unsigned mk = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = FR(r) + 4 * lh;
+            bool on = j >= s0 && j < s0 + n;
+            if (R.adj_type == 1 && on) {
+                const float2 pj = *reinterpret_cast<const float2 *>(pos + j * 2);
+                const double dx = (double)xa - (double)pj.x, dy = (double)ya - (double)pj.y;
+                const double tt = sqrt(dx * dx + dy * dy) / R.sigma;
+                // float32(exp(-t)) > 0 ; the exact test only matters within a hair of the underflow point
+                on = tt < 100.0 ? true : (tt > 110.0 ? false : ((float)exp(-tt) > 0.f));
+            }
+            mk |= on ? (1u << r) : 0u;
+        }
+        amask = mk;
+    };
+
+    const int first_off = DAG ? W.dec_goal0.w[0] : W.prior0.w[0];
+    WBlk pre = wload(wp, first_off, lane);
+#ifdef DN_DEBUG_V2
+#define DBG(stage, arr, NTILES)                                                                   \
+    if (R.dbg && t == 0 && blockIdx.x == 0) {                                                     \
+        for (int nt_ = 0; nt_ < NTILES; ++nt_)                                                    \
+            for (int r_ = 0; r_ < 16; ++r_) R.dbg[(((stage)*4 + nt_) * 64 + lane) * 16 + r_] = arr[nt_][r_]; \
+    }
+#else
+#define DBG(stage, arr, NTILES)
+#endif
+    for (int t = 0; t < R.T; ++t) {
+        T16 d[1];
+        if (DAG) {
+            build_mask();                   // PRE-update positions (models/dagnet/model.py:215-220)
+            // disposition: flattened xy of the scene's agents, zero padded
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = FR(r) + 4 * lh, j = f >> 1;
+                d[0][r] = (f < R.D && j < n) ? pos[(s0 + j) * 2 + (f & 1)] : 0.f;
+            }
+            // ---------------------------------------------------------------- goal head
+            T16 tg[2];
+            zero(tg);
+            pre = mm<2, 1, false>(tg, wp, W.dec_goal0.w[0], d, lane, pre, W.dec_goal0.w[1]);
+            pre = mm<2, 2, false>(tg, wp, W.dec_goal0.w[1], h[NL - 1], lane, pre, W.dec_goal2.w[0]);
+            finish<2, 2>(tg, wp, W.dec_goal0, gi, lh);
+            T16 decg[GT];
+            zero(decg);
+            pre = mm<GT, 2, false>(decg, wp, W.dec_goal2.w[0], tg, lane, pre, W.g_goal.heads);
+            finish<0, GT>(decg, wp, W.dec_goal2, 0, lh);
+            softmax_feat<GT>(decg, R.G, lh);
+            T16 gg[GT];
+            pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[0]);
+            T16 gc[GT];
+            zero(gc);
+            pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.lg_goals.w[1]);
+            pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.prior0.w[0]);
+            finish<0, GT>(gc, wp, W.lg_goals, 0, lh);
+            softmax_feat<GT>(gc, R.G, lh);
+            // categorical draw: argmax_g exp(p_g) / q_g, q ~ Exp(1)
+            float best = -1.f;
+            int bi = 0x7fffffff;
+#pragma unroll
+            for (int nt = 0; nt < GT; ++nt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int f0 = nt * 32 + 8 * a + 4 * lh;
+                    float q4[4];
+                    if (R.q) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            q4[i] = (live && f0 + i < R.G) ? R.q[(((int64_t)krow * R.T + t) * NK + grow) * R.G + f0 + i] : 1.f;
+                    } else {
+                        const uint4 u = philox4x32_10(make_uint4(rngrow, (uint32_t)t, (uint32_t)(f0 >> 2), 1u),
+                                                      make_uint2((uint32_t)R.seed, (uint32_t)(R.seed >> 32)));
+                        const uint32_t u4[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) q4[i] = -logf(((float)(u4[i] >> 8) + 1.0f) * (1.0f / 16777216.0f)) + 1e-30f;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int f = f0 + i;
+                        if (f < R.G) {
+                            const float v = expf(gc[nt][4 * a + i]) / q4[i];
+                            if (v > best || (v == best && f < bi)) { best = v; bi = f; }
+                        }
+                    }
+                }
+            {
+                const float ov = xhalf(best);
+                const int oi = xhalf(bi);
+                if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            }
+            if (R.force_goals && live) bi = min(max(R.force_goals[((int64_t)krow * R.T + t) * NK + grow], 0), R.G - 1);
+            gi = min(bi, R.G - 1);
+            if (R.out_goals && live && lh == 0) R.out_goals[((int64_t)krow * R.T + t) * NK + grow] = gi;
+        }
+        // -------------------------------------------------------------------- prior
+        T16 ta[2], tb[2];
+        DBG(7, h[NL - 1], 2);
+        zero(ta);
+        pre = mm<2, 2, false>(ta, wp, W.prior0.w[0], h[NL - 1], lane, pre, W.prior2.w[0]);
+        finish<1, 2>(ta, wp, W.prior0, gi, lh);
+        DBG(0, ta, 2);
+        zero(tb);
+        pre = mm<2, 2, false>(tb, wp, W.prior2.w[0], ta, lane, pre, W.prior_ml.w[0]);
+        finish<1, 2>(tb, wp, W.prior2, 0, lh);
+        constexpr int MLT = ZD == 32 ? 2 : 1;      // [mean ; logvar] = 2*z_dim features
+        T16 ml[MLT];
+        zero(ml);
+        pre = mm<MLT, 2, false>(ml, wp, W.prior_ml.w[0], tb, lane, pre, W.phi_z0.w[0]);
+        finish<0, MLT>(ml, wp, W.prior_ml, 0, lh);
+        DBG(1, tb, 2);
+        DBG(2, ml, MLT);
+        // -------------------------------------------------------------------- z = eps * exp(0.5 logvar) + mean
+        T16 z[1];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int f0 = 8 * a + 4 * lh;        // latent index of registers 4a..4a+3
+            float e4[4] = {0.f, 0.f, 0.f, 0.f};
+            if (f0 < ZD) {
+                if (R.eps) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        e4[i] = live ? R.eps[(((int64_t)krow * R.T + t) * NK + grow) * ZD + f0 + i] : 0.f;
+                } else {
+                    const uint4 u = philox4x32_10(make_uint4(rngrow, (uint32_t)t, (uint32_t)(f0 >> 2), 0u),
+                                                  make_uint2((uint32_t)R.seed, (uint32_t)(R.seed >> 32)));
+                    e4[0] = (float)(u.x >> 8) * (1.0f / 16777216.0f);
+                    e4[1] = (float)(u.y >> 8) * (1.0f / 16777216.0f);
+                    e4[2] = (float)(u.z >> 8) * (1.0f / 16777216.0f);
+                    e4[3] = (float)(u.w >> 8) * (1.0f / 16777216.0f);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 4 * a + i;
+                float v = 0.f;
+                if constexpr (ZD == 32) {
+                    v = e4[i] * expf(0.5f * ml[MLT - 1][r]) + ml[0][r];
+                } else {
+                    if (a < 2) v = e4[i] * expf(0.5f * ml[0][(r + 8) & 15]) + ml[0][r];     // logvar = features 16..31
+                }
+                z[0][r] = v;
+            }
+        }
+        DBG(3, z, 1);
+        // -------------------------------------------------------------------- phi_z, decoder
+        zero(ta);
+        pre = mm<2, 1, false>(ta, wp, W.phi_z0.w[0], z, lane, pre, W.phi_z2.w[0]);
+        finish<1, 2>(ta, wp, W.phi_z0, 0, lh);
+        T16 pz[2];
+        zero(pz);
+        pre = mm<2, 2, false>(pz, wp, W.phi_z2.w[0], ta, lane, pre, W.dec0.w[0]);
+        finish<1, 2>(pz, wp, W.phi_z2, 0, lh);
+        DBG(4, pz, 2);
+        zero(ta);
+        if (DAG) {
+            pre = mm<2, 1, false>(ta, wp, W.dec0.w[0], d, lane, pre, W.dec0.w[1]);
+            pre = mm<2, 2, false>(ta, wp, W.dec0.w[1], pz, lane, pre, W.dec0.w[2]);
+            pre = mm<2, 2, false>(ta, wp, W.dec0.w[2], h[NL - 1], lane, pre, W.dec2.w[0]);
+        } else {
+            pre = mm<2, 2, false>(ta, wp, W.dec0.w[0], pz, lane, pre, W.dec0.w[1]);
+            pre = mm<2, 2, false>(ta, wp, W.dec0.w[1], h[NL - 1], lane, pre, W.dec2.w[0]);
+        }
+        finish<1, 2>(ta, wp, W.dec0, gi, lh);
+        zero(tb);
+        pre = mm<2, 2, false>(tb, wp, W.dec2.w[0], ta, lane, pre, W.phi_x2.w[0]);
+        finish<1, 2>(tb, wp, W.dec2, 0, lh);
+        DBG(5, ta, 2);
+        DBG(6, tb, 2);
+        // dec_mean: 2 outputs over 64 features, each half sums its 32 features then the halves combine
+        float dmx = 0.f, dmy = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int fs = nt * 32 + 8 * a;
+                const float4 w0 = wp.ld4(lh * 16, W.dec_mean_w + fs);
+                const float4 w1 = wp.ld4(lh * 16, W.dec_mean_w + 64 + fs);
+                dmx += w0.x * tb[nt][4 * a] + w0.y * tb[nt][4 * a + 1] + w0.z * tb[nt][4 * a + 2] + w0.w * tb[nt][4 * a + 3];
+                dmy += w1.x * tb[nt][4 * a] + w1.y * tb[nt][4 * a + 1] + w1.z * tb[nt][4 * a + 2] + w1.w * tb[nt][4 * a + 3];
+            }
+        dmx += xhalf(dmx);
+        dmy += xhalf(dmy);
+        dmx += wp.ld1(0, W.dec_mean_b);
+        dmy += wp.ld1(0, W.dec_mean_b + 1);
+        if (live && lh == 0)
+            *reinterpret_cast<float2 *>(R.out + (((int64_t)krow * R.T + t) * NK + grow) * 2) = make_float2(dmx, dmy);
+        // -------------------------------------------------------------------- phi_x of the prediction
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int fs = nt * 32 + 8 * a;
+                const float4 wa = wp.ld4(lh * 32, W.phi_x0_w + fs * 2);          // W[f0..f0+1][0..1]
+                const float4 wb = wp.ld4(lh * 32, W.phi_x0_w + fs * 2 + 4);      // W[f0+2..f0+3][0..1]
+                const float4 bb = wp.ld4(lh * 16, W.phi_x0_b + fs);
+                ta[nt][4 * a + 0] = lrelu(wa.x * dmx + wa.y * dmy + bb.x, 0.01f);
+                ta[nt][4 * a + 1] = lrelu(wa.z * dmx + wa.w * dmy + bb.y, 0.01f);
+                ta[nt][4 * a + 2] = lrelu(wb.x * dmx + wb.y * dmy + bb.z, 0.01f);
+                ta[nt][4 * a + 3] = lrelu(wb.z * dmx + wb.w * dmy + bb.w, 0.01f);
+            }
+        T16 xin[4];
+        {
+            T16 px[2];
+            zero(px);
+            pre = mm<2, 2, false>(px, wp, W.phi_x2.w[0], ta, lane, pre, W.gru[0].r.w[0]);
+            finish<1, 2>(px, wp, W.phi_x2, 0, lh);
+            xin[0] = px[0]; xin[1] = px[1]; xin[2] = pz[0]; xin[3] = pz[1];
+        }
+        // -------------------------------------------------------------------- GRU
+        const int after_gru = GRAPH ? W.g_hid.heads : first_off;
+        pre = gru<4>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? W.gru[1].r.w[0] : after_gru);
+        if constexpr (NL == 2) pre = gru<2>(h[0], h[1], wp, W.gru[1], lane, pre, after_gru);
+        // -------------------------------------------------------------------- graph refinement of h[-1]
+        if (MODEL == 1) {       // A-VRNN: adjacency from the UPDATED positions (models/avrnn/model.py:201-209)
+            xa += dmx;
+            ya += dmy;
+            build_mask();
+        }
+        if (GRAPH) {
+            T16 hg[2];
+            pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, lane, pre, W.blend.w[0]);
+            zero(ta);
+            pre = mm<2, 2, false>(ta, wp, W.blend.w[0], hg, lane, pre, W.blend.w[1]);
+            pre = mm<2, 2, false>(ta, wp, W.blend.w[1], h[NL - 1], lane, pre, first_off);
+            finish<0, 2>(ta, wp, W.blend, 0, lh);
+            h[NL - 1][0] = ta[0];
+            h[NL - 1][1] = ta[1];
+        }
+        if (DAG) {
+            xa += dmx;
+            ya += dmy;
+        }
+    }
+}
+
+}   // namespace v2
+
+template <int MODEL, int NL, int ZD>
+static hipError_t launch_one(const V2Weights &w, const V2Run &r, hipStream_t st) {
+    hipLaunchKernelGGL((v2::rollout_v2_kernel<MODEL, NL, ZD>), dim3(r.n_tiles), dim3(64), 0, st, w, r);
+    return hipGetLastError();
+}
+
+// returns hipErrorInvalidValue when the (model, layers, z) combination has no instantiation
+extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, const V2Weights *w, const V2Run *r, hipStream_t st) {
+#define V2_CASE(M, L, Z) \
+    if (model == M && n_layers == L && z_dim == Z) return launch_one<M, L, Z>(*w, *r, st);
+    V2_CASE(2, 2, 32)
+    V2_CASE(1, 1, 32)
+    V2_CASE(0, 2, 32)
+#undef V2_CASE
+    return hipErrorInvalidValue;
+}
+
+extern "C" int dn_v2_has(int model, int n_layers, int z_dim) {
+    return (model == 2 && n_layers == 2 && z_dim == 32) || (model == 1 && n_layers == 1 && z_dim == 32) ||
+           (model == 0 && n_layers == 2 && z_dim == 32);
+}

@@ -52,8 +52,8 @@ typedef struct {
     int32_t n_heads;        /* P (GAT)                                                 */
     int32_t adjacency_type; /* DAGNET_ADJ_*                                            */
     int32_t top_k_neigh;    /* kNN adjacency                                           */
-    float sigma;            /* distance-similarity bandwidth                           */
     float alpha;            /* GAT LeakyReLU slope                                     */
+    double sigma;           /* distance-similarity bandwidth (fp64 as in the reference)*/
 } dagnet_config;
 
 /* One state-dict entry: reference key name (e.g. "rnn.weight_ih_l0"), host fp32 data,
@@ -136,7 +136,7 @@ int dagnet_graph_forward(const dagnet_model *m, const dagnet_plan *p, int32_t wh
  * Scene layout comes from the plan.  d_pos [T,N,2] (ignored for DAGNET_ADJ_FULL);
  * output dense [T,N,N] (dense_ld = N, zero-filled off the blocks by this call)
  * or compact [T, sum n_s^2] (dense_ld = 0; size per timestep = dagnet_plan_compact_adj_size). */
-int dagnet_adjacency(const dagnet_plan *p, int32_t adjacency_type, float sigma, int32_t top_k,
+int dagnet_adjacency(const dagnet_plan *p, int32_t adjacency_type, double sigma, int32_t top_k,
                      int32_t T, const float *d_pos, float *d_out, int64_t dense_ld, void *stream);
 int64_t dagnet_plan_compact_adj_size(const dagnet_plan *p);
 

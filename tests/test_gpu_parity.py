@@ -77,8 +77,9 @@ def test_sample_matches_reference(name):
                           eps=eps_s[1], q=q_s[1].to(DEV))
     assert s.shape == gold["samples"].shape
     _close(s.cpu(), gold["samples"], DISP_ATOL, DISP_RTOL, "samples")
-    # the reference-signature single-sample call is the K=1 slice of the batched launch
-    assert torch.equal(s1, s[1])
+    # the reference-signature single-sample call is the K=1 slice of the batched launch (a scene may sit
+    # at another position of its tile, which reorders the attention sums: equal to rounding, not bitwise)
+    _close(s1.cpu(), s[1].cpu(), 2e-6, 1e-5, "sample() vs sample_k()[1]")
     # metrics (relative_to_abs + ADE/FDE raw + min-over-K per scene)
     from dagnet_amd import _capi
     from dagnet_amd._runtime import scene_ptr_from_sse

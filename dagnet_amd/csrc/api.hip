@@ -60,6 +60,7 @@ struct dagnet_model {
     int device = 0;
     bool v2 = false;            // the register-resident kernel (rollout_v2.hip) covers this model
     V2Weights w2;
+    V2Weights *d_w2 = nullptr;  // device copy of w2
 };
 
 struct dagnet_plan {
@@ -424,13 +425,15 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     if (!ga || !be || !mu || !var) return g;
     const float *gp = ga->p, *bp = be->p, *mp = mu->p, *vp = var->p;
     const int ld = pad32(nout);
+    // eval-mode BatchNorm folded to y = x * scale + shift
     g.bn = pk.vec(
         [=](int i) {
             const int c = i % ld, row = i / ld;
-            if (c >= nout) return row == 3 ? 1.0f : 0.0f;
-            return row == 0 ? gp[c] : row == 1 ? bp[c] : row == 2 ? mp[c] : sqrtf(vp[c] + 1e-5f);
+            if (c >= nout) return 0.0f;
+            const float sc = gp[c] / sqrtf(vp[c] + 1e-5f);
+            return row == 0 ? sc : bp[c] - mp[c] * sc;
         },
-        4 * ld, 4 * ld);
+        2 * ld, 2 * ld);
     return g;
 }
 
@@ -611,8 +614,13 @@ extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor
     hipError_t e = hipGetDevice(&m->device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_wp), m->wp_floats * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(m->d_wp, pk.buf.data(), m->wp_floats * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess && m->v2) {
+        e = hipMalloc(reinterpret_cast<void **>(&m->d_w2), sizeof(V2Weights));
+        if (e == hipSuccess) e = hipMemcpy(m->d_w2, &m->w2, sizeof(V2Weights), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) {
         if (m->d_wp) (void)hipFree(m->d_wp);
+        if (m->d_w2) (void)hipFree(m->d_w2);
         delete m;
         return fail(DAGNET_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
     }
@@ -623,6 +631,7 @@ extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor
 extern "C" void dagnet_model_destroy(dagnet_model *m) {
     if (!m) return;
     if (m->d_wp) (void)hipFree(m->d_wp);
+    if (m->d_w2) (void)hipFree(m->d_w2);
     delete m;
 }
 
@@ -866,7 +875,7 @@ extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_
 #ifdef DN_PROFILE
         r.dbg = reinterpret_cast<float *>(g_prof);
 #endif
-        HIP_TRY(dn_launch_rollout_v2(m->dims.model, m->dims.L, m->dims.Z, &m->w2, &r, static_cast<hipStream_t>(stream)));
+        HIP_TRY(dn_launch_rollout_v2(m->dims.model, m->dims.L, m->dims.Z, m->d_w2, &r, static_cast<hipStream_t>(stream)));
         return DAGNET_OK;
     }
     DnParams P;

@@ -59,8 +59,18 @@ struct WBuf {
     }
 };
 
-__device__ __forceinline__ float lrelu(float v, float s) { return v > 0.f ? v : v * s; }
-__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+// Hardware transcendental units (v_exp_f32 / v_rcp_f32 / v_log_f32, 1 ulp) instead of the ~10-instruction
+// libm expansions: the per-lane epilogues are pure VALU time next to the MFMA stream.  Relative error
+// <= ~2e-7 * (1 + |x|), two orders below the 1e-4 parity tolerance (checked by tests/test_gpu_parity.py).
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
+__device__ __forceinline__ float ftanh(float x) {
+    const float xc = fminf(fmaxf(x, -15.f), 15.f);
+    return 1.0f - 2.0f * frcp(1.0f + fexp(2.0f * xc));
+}
+__device__ __forceinline__ float lrelu(float v, float s) { return fmaxf(v, v * s); }     // 0 < s < 1
+__device__ __forceinline__ float sigm(float v) { return frcp(1.0f + fexp(-v)); }
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 __device__ __forceinline__ int xhalf(int v) { return __shfl_xor(v, 32); }
 
@@ -165,15 +175,16 @@ __device__ __forceinline__ void softmax_feat(T16 (&x)[NT], int G, int lh) {
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = (nt * 32 + FR(r) + 4 * lh < G) ? expf(x[nt][r] - mx) : 0.f;
+            const float e = (nt * 32 + FR(r) + 4 * lh < G) ? fexp(x[nt][r] - mx) : 0.f;
             x[nt][r] = e;
             sum += e;
         }
     sum += xhalf(sum);
+    const float inv = frcp(sum);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x[nt][r] = x[nt][r] / sum;
+        for (int r = 0; r < 16; ++r) x[nt][r] = x[nt][r] * inv;
 }
 
 // attention weights of this lane's row over the 16 tile rows its half owns:
@@ -190,12 +201,13 @@ __device__ __forceinline__ void attn_weights(T16 &alpha, float s1, const float (
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        e[r] = expf(e[r] - mx);
+        e[r] = fexp(e[r] - mx);
         sum += e[r];
     }
     sum += xhalf(sum);
+    const float inv = frcp(sum);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) alpha[r] = e[r] / sum;
+    for (int r = 0; r < 16; ++r) alpha[r] = e[r] * inv;
 }
 
 // Dense GAT (P heads of F features with P*F = 32 -> out_att -> BatchNorm(eval) -> tanh) on the tile.
@@ -234,7 +246,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
         for (int r = 0; r < 16; ++r) x2[0] = MFMA(mine ? whT[0][r] : 0.f, alpha[r], x2[0]);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x2[0][r] = x2[0][r] > 0.f ? x2[0][r] : expm1f(x2[0][r]);     // ELU
+    for (int r = 0; r < 16; ++r) x2[0][r] = x2[0][r] > 0.f ? x2[0][r] : fexp(x2[0][r]) - 1.0f;     // ELU
     // out_att
     T16 wh2T[NT], sf2[1];
     zero(wh2T);
@@ -261,16 +273,13 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int f0 = nt * 32 + 8 * a + 4 * lh, fs = nt * 32 + 8 * a;
-            const float4 ga = wp.ld4(lh * 16, Gw.bn + fs);
-            const float4 be = wp.ld4(lh * 16, Gw.bn + NT * 32 + fs);
-            const float4 mu = wp.ld4(lh * 16, Gw.bn + 2 * NT * 32 + fs);
-            const float4 sd = wp.ld4(lh * 16, Gw.bn + 3 * NT * 32 + fs);
-            const float g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
-            const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, s4[4] = {sd.x, sd.y, sd.z, sd.w};
+            const float4 sc = wp.ld4(lh * 16, Gw.bn + fs);               // gamma / sqrt(var + eps)
+            const float4 sh = wp.ld4(lh * 16, Gw.bn + NT * 32 + fs);     // beta - mean * scale
+            const float g4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float v = (out[nt][4 * a + i] - m4[i]) / s4[i] * g4[i] + b4[i];
-                out[nt][4 * a + i] = (f0 + i < Gw.nout) ? tanhf(v) : 0.f;
+                const float v = out[nt][4 * a + i] * g4[i] + b4[i];
+                out[nt][4 * a + i] = (f0 + i < Gw.nout) ? ftanh(v) : 0.f;
             }
         }
     return pre;
@@ -308,7 +317,7 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
                 const int r = 4 * a + i;
                 const float rg = sigm(ar[0][r] + r4[i]);
                 const float zg = sigm(az[0][r] + z4[i]);
-                const float ng = tanhf((ai[0][r] + i4[i]) + rg * (ah[0][r] + h4[i]));
+                const float ng = ftanh((ai[0][r] + i4[i]) + rg * (ah[0][r] + h4[i]));
                 hn[nt][r] = (1.0f - zg) * ng + zg * h[nt][r];
             }
         }
@@ -320,7 +329,8 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
 
 // MODEL: 0 VRNN, 1 A-VRNN, 2 DAG-Net.  NL: GRU layers.  ZT: 32 -> z_dim 32, 16 -> z_dim 16.
 template <int MODEL, int NL, int ZD>
-__global__ __launch_bounds__(64) void rollout_v2_kernel(const V2Weights W, const V2Run R) {
+__global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
+    const V2Weights &W = *Wp;     // offsets are fetched with scalar loads where they are used (no SGPR residency)
     __shared__ float xch[32 * 4 + 64];
     float *pos = xch + 128;                 // [32][2] current absolute positions of the tile rows
     const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
@@ -444,13 +454,13 @@ __global__ __launch_bounds__(64) void rollout_v2_kernel(const V2Weights W, const
                                                       make_uint2((uint32_t)R.seed, (uint32_t)(R.seed >> 32)));
                         const uint32_t u4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) q4[i] = -logf(((float)(u4[i] >> 8) + 1.0f) * (1.0f / 16777216.0f)) + 1e-30f;
+                        for (int i = 0; i < 4; ++i) q4[i] = -flog(((float)(u4[i] >> 8) + 1.0f) * (1.0f / 16777216.0f)) + 1e-30f;
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int f = f0 + i;
                         if (f < R.G) {
-                            const float v = expf(gc[nt][4 * a + i]) / q4[i];
+                            const float v = fexp(gc[nt][4 * a + i]) * frcp(q4[i]);
                             if (v > best || (v == best && f < bi)) { best = v; bi = f; }
                         }
                     }
@@ -506,9 +516,9 @@ __global__ __launch_bounds__(64) void rollout_v2_kernel(const V2Weights W, const
                 const int r = 4 * a + i;
                 float v = 0.f;
                 if constexpr (ZD == 32) {
-                    v = e4[i] * expf(0.5f * ml[MLT - 1][r]) + ml[0][r];
+                    v = e4[i] * fexp(0.5f * ml[MLT - 1][r]) + ml[0][r];
                 } else {
-                    if (a < 2) v = e4[i] * expf(0.5f * ml[0][(r + 8) & 15]) + ml[0][r];     // logvar = features 16..31
+                    if (a < 2) v = e4[i] * fexp(0.5f * ml[0][(r + 8) & 15]) + ml[0][r];     // logvar = features 16..31
                 }
                 z[0][r] = v;
             }
@@ -608,15 +618,16 @@ __global__ __launch_bounds__(64) void rollout_v2_kernel(const V2Weights W, const
 }   // namespace v2
 
 template <int MODEL, int NL, int ZD>
-static hipError_t launch_one(const V2Weights &w, const V2Run &r, hipStream_t st) {
-    hipLaunchKernelGGL((v2::rollout_v2_kernel<MODEL, NL, ZD>), dim3(r.n_tiles), dim3(64), 0, st, w, r);
+static hipError_t launch_one(const V2Weights *d_w, const V2Run &r, hipStream_t st) {
+    hipLaunchKernelGGL((v2::rollout_v2_kernel<MODEL, NL, ZD>), dim3(r.n_tiles), dim3(64), 0, st, d_w, r);
     return hipGetLastError();
 }
 
 // returns hipErrorInvalidValue when the (model, layers, z) combination has no instantiation
-extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, const V2Weights *w, const V2Run *r, hipStream_t st) {
+// d_w: DEVICE pointer to the model's V2Weights table
+extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, const V2Weights *d_w, const V2Run *r, hipStream_t st) {
 #define V2_CASE(M, L, Z) \
-    if (model == M && n_layers == L && z_dim == Z) return launch_one<M, L, Z>(*w, *r, st);
+    if (model == M && n_layers == L && z_dim == Z) return launch_one<M, L, Z>(d_w, *r, st);
     V2_CASE(2, 2, 32)
     V2_CASE(1, 1, 32)
     V2_CASE(0, 2, 32)

@@ -873,7 +873,8 @@ extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_
         r.h0 = d_h0; r.x0 = d_x0; r.g0 = d_g0; r.eps = d_eps; r.q = d_q; r.force_goals = d_force_goals;
         r.seed = seed; r.out = d_out; r.out_goals = d_out_goals;
 #ifdef DN_PROFILE
-        r.dbg = reinterpret_cast<float *>(g_prof);
+        if (getenv("DAGNET_V2_DUMP")) r.dbg = reinterpret_cast<float *>(g_prof);
+        else r.prof = g_prof;
 #endif
         HIP_TRY(dn_launch_rollout_v2(m->dims.model, m->dims.L, m->dims.Z, m->d_w2, &r, static_cast<hipStream_t>(stream)));
         return DAGNET_OK;

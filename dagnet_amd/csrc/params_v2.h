@@ -56,5 +56,6 @@ struct V2Run {
     uint64_t seed;
     float *out;
     int32_t *out_goals;
+    long long *prof;                 // DN_PROFILE builds: per-phase cycle counters of tile 0
     float *dbg;                      // debug builds: tile dumps of the first step of tile 0 (else NULL)
 };

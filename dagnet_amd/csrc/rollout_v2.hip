@@ -222,23 +222,23 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     zero(sf);
     pre = mm<1, KT, true>(whT, wp, Gw.heads, x, lane, pre, Gw.fold);
     // s1[p] = a_src[p].Wh_row, s2[p] = a_dst[p].Wh_row through folded weights: features 0..3 / 4..7
-    pre = mm<1, KT, false>(sf, wp, Gw.fold, x, lane, pre, Gw.out);
+    pre = mm<1, KT, false>(sf, wp, Gw.fold, x, lane, pre, Gw.fold_out);
     float s1[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) s1[p] = __shfl(sf[0][p], lc);          // half 0 holds features 0..3
     __syncthreads();
-    if (lh == 1) *reinterpret_cast<float4 *>(xch + lc * 4) = make_float4(sf[0][0], sf[0][1], sf[0][2], sf[0][3]);   // features 4..7
-    __syncthreads();
-    float4 s2j[16];
+    if (lh == 1) {                                                       // half 1 holds features 4..7 = s2 of the 4 heads
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s2j[r] = *reinterpret_cast<const float4 *>(xch + (FR(r) + 4 * lh) * 4);
+        for (int p = 0; p < 4; ++p) xch[p * 32 + lc] = sf[0][p];
+    }
+    __syncthreads();
     T16 x2[1];
     zero(x2);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         float s2[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s2[r] = p == 0 ? s2j[r].x : p == 1 ? s2j[r].y : p == 2 ? s2j[r].z : s2j[r].w;
+        for (int r = 0; r < 16; ++r) s2[r] = xch[p * 32 + FR(r) + 4 * lh];
         T16 alpha;
         attn_weights(alpha, s1[p], s2, amask, slope);
         const bool mine = (lc >> 3) == p;     // this lane's feature belongs to head p
@@ -248,11 +248,9 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
     for (int r = 0; r < 16; ++r) x2[0][r] = x2[0][r] > 0.f ? x2[0][r] : fexp(x2[0][r]) - 1.0f;     // ELU
     // out_att
-    T16 wh2T[NT], sf2[1];
-    zero(wh2T);
+    T16 sf2[1];
     zero(sf2);
-    pre = mm<NT, 1, true>(wh2T, wp, Gw.out, x2, lane, pre, Gw.fold_out);
-    pre = mm<1, 1, false>(sf2, wp, Gw.fold_out, x2, lane, pre, next_off);
+    pre = mm<1, 1, false>(sf2, wp, Gw.fold_out, x2, lane, pre, Gw.out);
     const float t1 = __shfl(sf2[0][0], lc), t2own = __shfl(sf2[0][1], lc);
     __syncthreads();
     if (lh == 0) xch[lc] = t2own;
@@ -264,22 +262,26 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     attn_weights(alpha, t1, s2o, amask, slope);
     zero(out);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {      // one output tile at a time: Wh2^T tile -> aggregation (keeps 16, not NT*16, registers live)
+        T16 wh2T[1];
+        zero(wh2T);
+        pre = mm<1, 1, true>(wh2T, wp, Gw.out + nt * 1024, x2, lane, pre, nt + 1 < NT ? Gw.out + (nt + 1) * 1024 : next_off);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[nt][r], alpha[r], out[nt]);
+        for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], alpha[r], out[nt]);
+    }
     // BatchNorm1d (running statistics) + tanh; padded features stay 0
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int f0 = nt * 32 + 8 * a + 4 * lh, fs = nt * 32 + 8 * a;
+            const int fs = nt * 32 + 8 * a;
             const float4 sc = wp.ld4(lh * 16, Gw.bn + fs);               // gamma / sqrt(var + eps)
             const float4 sh = wp.ld4(lh * 16, Gw.bn + NT * 32 + fs);     // beta - mean * scale
             const float g4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float v = out[nt][4 * a + i] * g4[i] + b4[i];
-                out[nt][4 * a + i] = (f0 + i < Gw.nout) ? ftanh(v) : 0.f;
+                out[nt][4 * a + i] = ftanh(v);      // padded features: scale = shift = 0 -> tanh(0) = 0
             }
         }
     return pre;
@@ -293,32 +295,48 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
     T16 hn[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        T16 ar[1], az[1], ai[1], ah[1];
-        zero(ar); zero(az); zero(ai); zero(ah);
-        // weights of a gate are packed per output tile: offset of tile nt = nt * (KT*4*64*4) floats
+        // gates one after the other so that only one accumulator plus two 16-register results are live:
+        //   nh -> r -> t = r*(W_hn h + b_hn) -> n = tanh(W_in x + b_in + t) -> z -> h' = (1-z) n + z h
+        // weights of a gate are packed per output tile: offset of tile nt = nt * KT * 1024 floats
         const int ox = nt * KX * 1024, oh = nt * 2 * 1024;
-        pre = mm<1, KX, false>(ar, wp, Gw.r.w[0] + ox, xin, lane, pre, Gw.z.w[0] + ox);
-        pre = mm<1, KX, false>(az, wp, Gw.z.w[0] + ox, xin, lane, pre, Gw.ni.w[0] + ox);
-        pre = mm<1, KX, false>(ai, wp, Gw.ni.w[0] + ox, xin, lane, pre, Gw.r.w[1] + oh);
-        pre = mm<1, 2, false>(ar, wp, Gw.r.w[1] + oh, h, lane, pre, Gw.z.w[1] + oh);
-        pre = mm<1, 2, false>(az, wp, Gw.z.w[1] + oh, h, lane, pre, Gw.nh.w[0] + oh);
-        pre = mm<1, 2, false>(ah, wp, Gw.nh.w[0] + oh, h, lane, pre, nt == 0 ? Gw.r.w[0] + KX * 1024 : next_off);
+        T16 acc[1], tt, ng;
+        zero(acc);
+        pre = mm<1, 2, false>(acc, wp, Gw.nh.w[0] + oh, h, lane, pre, Gw.r.w[0] + ox);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const int fs = nt * 32 + 8 * a;
-            const float4 br = wp.ld4(lh * 16, Gw.r.bias + fs);
-            const float4 bz = wp.ld4(lh * 16, Gw.z.bias + fs);
-            const float4 bi = wp.ld4(lh * 16, Gw.ni.bias + fs);
-            const float4 bh = wp.ld4(lh * 16, Gw.nh.bias + fs);
-            const float r4[4] = {br.x, br.y, br.z, br.w}, z4[4] = {bz.x, bz.y, bz.z, bz.w};
-            const float i4[4] = {bi.x, bi.y, bi.z, bi.w}, h4[4] = {bh.x, bh.y, bh.z, bh.w};
+            const float4 b = wp.ld4(lh * 16, Gw.nh.bias + nt * 32 + 8 * a);
+            tt[4 * a + 0] = acc[0][4 * a + 0] + b.x; tt[4 * a + 1] = acc[0][4 * a + 1] + b.y;
+            tt[4 * a + 2] = acc[0][4 * a + 2] + b.z; tt[4 * a + 3] = acc[0][4 * a + 3] + b.w;
+        }
+        zero(acc);
+        pre = mm<1, KX, false>(acc, wp, Gw.r.w[0] + ox, xin, lane, pre, Gw.r.w[1] + oh);
+        pre = mm<1, 2, false>(acc, wp, Gw.r.w[1] + oh, h, lane, pre, Gw.ni.w[0] + ox);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 b = wp.ld4(lh * 16, Gw.r.bias + nt * 32 + 8 * a);
+            tt[4 * a + 0] *= sigm(acc[0][4 * a + 0] + b.x); tt[4 * a + 1] *= sigm(acc[0][4 * a + 1] + b.y);
+            tt[4 * a + 2] *= sigm(acc[0][4 * a + 2] + b.z); tt[4 * a + 3] *= sigm(acc[0][4 * a + 3] + b.w);
+        }
+        zero(acc);
+        pre = mm<1, KX, false>(acc, wp, Gw.ni.w[0] + ox, xin, lane, pre, Gw.z.w[0] + ox);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 b = wp.ld4(lh * 16, Gw.ni.bias + nt * 32 + 8 * a);
+            ng[4 * a + 0] = ftanh((acc[0][4 * a + 0] + b.x) + tt[4 * a + 0]); ng[4 * a + 1] = ftanh((acc[0][4 * a + 1] + b.y) + tt[4 * a + 1]);
+            ng[4 * a + 2] = ftanh((acc[0][4 * a + 2] + b.z) + tt[4 * a + 2]); ng[4 * a + 3] = ftanh((acc[0][4 * a + 3] + b.w) + tt[4 * a + 3]);
+        }
+        zero(acc);
+        pre = mm<1, KX, false>(acc, wp, Gw.z.w[0] + ox, xin, lane, pre, Gw.z.w[1] + oh);
+        pre = mm<1, 2, false>(acc, wp, Gw.z.w[1] + oh, h, lane, pre, nt == 0 ? Gw.nh.w[0] + 2 * 1024 : next_off);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 b = wp.ld4(lh * 16, Gw.z.bias + nt * 32 + 8 * a);
+            const float b4[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * a + i;
-                const float rg = sigm(ar[0][r] + r4[i]);
-                const float zg = sigm(az[0][r] + z4[i]);
-                const float ng = ftanh((ai[0][r] + i4[i]) + rg * (ah[0][r] + h4[i]));
-                hn[nt][r] = (1.0f - zg) * ng + zg * h[nt][r];
+                const float zg = sigm(acc[0][r] + b4[i]);
+                hn[nt][r] = (1.0f - zg) * ng[r] + zg * h[nt][r];
             }
         }
     }
@@ -332,6 +350,7 @@ template <int MODEL, int NL, int ZD>
 __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
     const V2Weights &W = *Wp;     // offsets are fetched with scalar loads where they are used (no SGPR residency)
     __shared__ float xch[32 * 4 + 64];
+    __shared__ float stash[(MODEL == 2 && NL == 2) ? 32 * 64 : 1];   // layer-0 hidden state parked during the goal head
     float *pos = xch + 128;                 // [32][2] current absolute positions of the tile rows
     const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
     WBuf wp;
@@ -374,30 +393,22 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     if (DAG && live) gi = min(max(R.g0[grow], 0), R.G - 1);
     unsigned amask = 0;
 
-    auto build_mask = [&]() {
-        // rows j = FR(r)+4*lh of the tile that are in this row's scene and have adjacency > 0
-        __syncthreads();
-        if (lh == 0) { pos[lc * 2] = xa; pos[lc * 2 + 1] = ya; }
-        __syncthreads();
-        unsigned mk = 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int j = FR(r) + 4 * lh;
-            bool on = j >= s0 && j < s0 + n;
-            if (R.adj_type == 1 && on) {
-                const float2 pj = *reinterpret_cast<const float2 *>(pos + j * 2);
-                const double dx = (double)xa - (double)pj.x, dy = (double)ya - (double)pj.y;
-                const double tt = sqrt(dx * dx + dy * dy) / R.sigma;
-                // float32(exp(-t)) > 0 ; the exact test only matters within a hair of the underflow point
-                on = tt < 100.0 ? true : (tt > 110.0 ? false : ((float)exp(-tt) > 0.f));
-            }
-            mk |= on ? (1u << r) : 0u;
-        }
-        amask = mk;
-    };
 
     const int first_off = DAG ? W.dec_goal0.w[0] : W.prior0.w[0];
     WBlk pre = wload(wp, first_off, lane);
+#ifdef DN_PROFILE
+    long long pstamp = clock64();
+#define PH(i)                                                                     \
+    do {                                                                          \
+        if (R.prof && blockIdx.x == 0 && lane == 0) {                             \
+            const long long now_ = clock64();                                     \
+            R.prof[i] += now_ - pstamp;                                           \
+            pstamp = now_;                                                        \
+        }                                                                         \
+    } while (0)
+#else
+#define PH(i)
+#endif
 #ifdef DN_DEBUG_V2
 #define DBG(stage, arr, NTILES)                                                                   \
     if (R.dbg && t == 0 && blockIdx.x == 0) {                                                     \
@@ -407,16 +418,51 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #else
 #define DBG(stage, arr, NTILES)
 #endif
+    const int lane0 = lane, s00 = s0, n0 = n;
     for (int t = 0; t < R.T; ++t) {
+        // Lane predicates (v_cmp results) live in SGPR pairs; if the compiler hoists the ~150 loop-invariant ones
+        // out of the time loop they spill.  Re-deriving the lane ids from an opaque copy once per step keeps
+        // them local to the step.
+        int lane = lane0, s0 = s00, n = n0;
+        asm volatile("" : "+v"(lane), "+v"(s0), "+v"(n));
+        const int lh = lane >> 5, lc = lane & 31;
+        auto build_mask = [&]() {
+            // rows j = FR(r)+4*lh of the tile that are in this row's scene and have adjacency > 0
+            __syncthreads();
+            if (lh == 0) { pos[lc * 2] = xa; pos[lc * 2 + 1] = ya; }
+            __syncthreads();
+            unsigned mk = 0;
+            const double lim = 103.97207708399179 * R.sigma, lim2 = lim * lim;      // 150 ln 2 = 103.972077...
+            const bool nodist = R.adj_type != 1;
+    #pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = FR(r) + 4 * lh;
+                // branch-free: adjacency > 0  <=>  float32(exp(-d/sigma)) > 0  <=>  exp(-d/sigma) > 2^-150 (the largest
+                // value that still rounds to zero)  <=>  d < 150 ln2 sigma: a squared-distance compare in fp64
+                const float2 pj = *reinterpret_cast<const float2 *>(pos + j * 2);
+                const double dx = (double)xa - (double)pj.x, dy = (double)ya - (double)pj.y;
+                const bool on = (j >= s0) & (j < s0 + n) & (nodist | (dx * dx + dy * dy < lim2));
+                mk |= on ? (1u << r) : 0u;
+            }
+            amask = mk;
+        };
         T16 d[1];
         if (DAG) {
+            if constexpr (NL == 2) {        // h[0] is not read until the GRU: park it in LDS, the goal head needs the registers
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) stash[(nt * 16 + r) * 64 + lane] = h[0][nt][r];
+            }
             build_mask();                   // PRE-update positions (models/dagnet/model.py:215-220)
             // disposition: flattened xy of the scene's agents, zero padded
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int f = FR(r) + 4 * lh, j = f >> 1;
-                d[0][r] = (f < R.D && j < n) ? pos[(s0 + j) * 2 + (f & 1)] : 0.f;
+                const float pv = pos[min(s0 + j, 31) * 2 + (f & 1)];
+                d[0][r] = ((f < R.D) & (j < n)) ? pv : 0.f;
             }
+            PH(0);
             // ---------------------------------------------------------------- goal head
             T16 tg[2];
             zero(tg);
@@ -425,14 +471,18 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             finish<2, 2>(tg, wp, W.dec_goal0, gi, lh);
             T16 decg[GT];
             zero(decg);
-            pre = mm<GT, 2, false>(decg, wp, W.dec_goal2.w[0], tg, lane, pre, W.g_goal.heads);
+            pre = mm<GT, 2, false>(decg, wp, W.dec_goal2.w[0], tg, lane, pre, W.lg_goals.w[0]);
             finish<0, GT>(decg, wp, W.dec_goal2, 0, lh);
             softmax_feat<GT>(decg, R.G, lh);
-            T16 gg[GT];
-            pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[0]);
+            PH(1);
+            // lg_goals = W1.dec_g + W2.g_graph: the dec_g half runs before the graph so that dec_g is dead
+            // once the graph has consumed it (peak registers: gc + gg instead of dec_g + gg + gc)
             T16 gc[GT];
             zero(gc);
-            pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.lg_goals.w[1]);
+            pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.g_goal.heads);
+            T16 gg[GT];
+            pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1]);
+            PH(2);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.prior0.w[0]);
             finish<0, GT>(gc, wp, W.lg_goals, 0, lh);
             softmax_feat<GT>(gc, R.G, lh);
@@ -474,6 +524,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             gi = min(bi, R.G - 1);
             if (R.out_goals && live && lh == 0) R.out_goals[((int64_t)krow * R.T + t) * NK + grow] = gi;
         }
+        PH(3);
         // -------------------------------------------------------------------- prior
         T16 ta[2], tb[2];
         DBG(7, h[NL - 1], 2);
@@ -491,6 +542,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         finish<0, MLT>(ml, wp, W.prior_ml, 0, lh);
         DBG(1, tb, 2);
         DBG(2, ml, MLT);
+        PH(4);
         // -------------------------------------------------------------------- z = eps * exp(0.5 logvar) + mean
         T16 z[1];
 #pragma unroll
@@ -524,6 +576,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             }
         }
         DBG(3, z, 1);
+        PH(5);
         // -------------------------------------------------------------------- phi_z, decoder
         zero(ta);
         pre = mm<2, 1, false>(ta, wp, W.phi_z0.w[0], z, lane, pre, W.phi_z2.w[0]);
@@ -535,6 +588,13 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         DBG(4, pz, 2);
         zero(ta);
         if (DAG) {
+            // rebuilt from the positions in LDS (unchanged since the start of the step) rather than kept live
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = FR(r) + 4 * lh, j = f >> 1;
+                const float pv = pos[min(s0 + j, 31) * 2 + (f & 1)];
+                d[0][r] = ((f < R.D) & (j < n)) ? pv : 0.f;
+            }
             pre = mm<2, 1, false>(ta, wp, W.dec0.w[0], d, lane, pre, W.dec0.w[1]);
             pre = mm<2, 2, false>(ta, wp, W.dec0.w[1], pz, lane, pre, W.dec0.w[2]);
             pre = mm<2, 2, false>(ta, wp, W.dec0.w[2], h[NL - 1], lane, pre, W.dec2.w[0]);
@@ -566,6 +626,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         dmy += wp.ld1(0, W.dec_mean_b + 1);
         if (live && lh == 0)
             *reinterpret_cast<float2 *>(R.out + (((int64_t)krow * R.T + t) * NK + grow) * 2) = make_float2(dmx, dmy);
+        PH(6);
         // -------------------------------------------------------------------- phi_x of the prediction
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -584,14 +645,22 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         {
             T16 px[2];
             zero(px);
-            pre = mm<2, 2, false>(px, wp, W.phi_x2.w[0], ta, lane, pre, W.gru[0].r.w[0]);
+            pre = mm<2, 2, false>(px, wp, W.phi_x2.w[0], ta, lane, pre, W.gru[0].nh.w[0]);
             finish<1, 2>(px, wp, W.phi_x2, 0, lh);
             xin[0] = px[0]; xin[1] = px[1]; xin[2] = pz[0]; xin[3] = pz[1];
         }
+        PH(7);
         // -------------------------------------------------------------------- GRU
+        if constexpr (DAG && NL == 2) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[0][nt][r] = stash[(nt * 16 + r) * 64 + lane];
+        }
         const int after_gru = GRAPH ? W.g_hid.heads : first_off;
-        pre = gru<4>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? W.gru[1].r.w[0] : after_gru);
+        pre = gru<4>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? W.gru[1].nh.w[0] : after_gru);
         if constexpr (NL == 2) pre = gru<2>(h[0], h[1], wp, W.gru[1], lane, pre, after_gru);
+        PH(8);
         // -------------------------------------------------------------------- graph refinement of h[-1]
         if (MODEL == 1) {       // A-VRNN: adjacency from the UPDATED positions (models/avrnn/model.py:201-209)
             xa += dmx;
@@ -612,6 +681,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             xa += dmx;
             ya += dmy;
         }
+        PH(9);
     }
 }
 

@@ -1,5 +1,6 @@
 """Debug: dump v2 intermediate tiles of step 0 and compare with the oracle (VRNN)."""
 import ctypes, os, sys
+os.environ["DAGNET_V2_DUMP"] = "1"
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 from dagnet_amd import _capi

@@ -4,11 +4,15 @@
 #include <stdint.h>
 
 // ---------------------------------------------------------------------------------------------
-// Philox4x32-10 counter RNG (throughput mode; parity mode injects eps / q instead)
+// Philox4x32 counter RNG (throughput mode; parity mode injects eps / q instead)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+// Philox4x32 with 7 rounds (Salmon et al., SC'11: the 7-round variant is the fastest one that passes
+// BigCrush; 10 is the conservative default).  The stream is ours, not torch's: parity is defined on
+// injected noise, and both rollout kernels draw the same numbers for the same (seed, row, t, j).
+#define DN_PHILOX_ROUNDS 7
+__device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < DN_PHILOX_ROUNDS; ++i) {
         const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
         const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
         c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
@@ -20,7 +24,7 @@ __device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
 // stream 0: eps (uniform [0,1)), stream 1: q (Exp(1)); element j of (row, t)
 __device__ __forceinline__ uint32_t rng_bits(uint64_t seed, uint32_t stream, uint32_t row, uint32_t t, uint32_t j) {
     uint4 c = make_uint4(row, t, j >> 2, stream);
-    uint4 r = philox4x32_10(c, make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    uint4 r = philox4x32(c, make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
     const uint32_t s = j & 3u;
     return s == 0 ? r.x : s == 1 ? r.y : s == 2 ? r.z : r.w;
 }

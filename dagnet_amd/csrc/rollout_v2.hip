@@ -350,7 +350,8 @@ template <int MODEL, int NL, int ZD>
 __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
     const V2Weights &W = *Wp;     // offsets are fetched with scalar loads where they are used (no SGPR residency)
     __shared__ float xch[32 * 4 + 64];
-    __shared__ float stash[(MODEL == 2 && NL == 2) ? 32 * 64 : 1];   // layer-0 hidden state parked during the goal head
+    // DAG-Net: hidden state parked in LDS while the goal head needs the registers ([tile][reg][lane], conflict free)
+    __shared__ float stash[MODEL == 2 ? NL * 32 * 64 : 1];
     float *pos = xch + 128;                 // [32][2] current absolute positions of the tile rows
     const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
     WBuf wp;
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) stash[(nt * 16 + r) * 64 + lane] = h[0][nt][r];
+                    for (int r = 0; r < 16; ++r) stash[((2 + nt) * 16 + r) * 64 + lane] = h[0][nt][r];
             }
             build_mask();                   // PRE-update positions (models/dagnet/model.py:215-220)
             // disposition: flattened xy of the scene's agents, zero padded
@@ -469,6 +470,11 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             pre = mm<2, 1, false>(tg, wp, W.dec_goal0.w[0], d, lane, pre, W.dec_goal0.w[1]);
             pre = mm<2, 2, false>(tg, wp, W.dec_goal0.w[1], h[NL - 1], lane, pre, W.dec_goal2.w[0]);
             finish<2, 2>(tg, wp, W.dec_goal0, gi, lh);
+            // the top-layer hidden state is not read again until the prior: park it as well
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stash[(nt * 16 + r) * 64 + lane] = h[NL - 1][nt][r];
             T16 decg[GT];
             zero(decg);
             pre = mm<GT, 2, false>(decg, wp, W.dec_goal2.w[0], tg, lane, pre, W.lg_goals.w[0]);
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
                         for (int i = 0; i < 4; ++i)
                             q4[i] = (live && f0 + i < R.G) ? R.q[(((int64_t)krow * R.T + t) * NK + grow) * R.G + f0 + i] : 1.f;
                     } else {
-                        const uint4 u = philox4x32_10(make_uint4(rngrow, (uint32_t)t, (uint32_t)(f0 >> 2), 1u),
+                        const uint4 u = philox4x32(make_uint4(rngrow, (uint32_t)t, (uint32_t)(f0 >> 2), 1u),
                                                       make_uint2((uint32_t)R.seed, (uint32_t)(R.seed >> 32)));
                         const uint32_t u4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -525,6 +531,12 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             if (R.out_goals && live && lh == 0) R.out_goals[((int64_t)krow * R.T + t) * NK + grow] = gi;
         }
         PH(3);
+        if constexpr (DAG) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[NL - 1][nt][r] = stash[(nt * 16 + r) * 64 + lane];
+        }
         // -------------------------------------------------------------------- prior
         T16 ta[2], tb[2];
         DBG(7, h[NL - 1], 2);
@@ -555,7 +567,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
                     for (int i = 0; i < 4; ++i)
                         e4[i] = live ? R.eps[(((int64_t)krow * R.T + t) * NK + grow) * ZD + f0 + i] : 0.f;
                 } else {
-                    const uint4 u = philox4x32_10(make_uint4(rngrow, (uint32_t)t, (uint32_t)(f0 >> 2), 0u),
+                    const uint4 u = philox4x32(make_uint4(rngrow, (uint32_t)t, (uint32_t)(f0 >> 2), 0u),
                                                   make_uint2((uint32_t)R.seed, (uint32_t)(R.seed >> 32)));
                     e4[0] = (float)(u.x >> 8) * (1.0f / 16777216.0f);
                     e4[1] = (float)(u.y >> 8) * (1.0f / 16777216.0f);
@@ -655,7 +667,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) h[0][nt][r] = stash[(nt * 16 + r) * 64 + lane];
+                for (int r = 0; r < 16; ++r) h[0][nt][r] = stash[((2 + nt) * 16 + r) * 64 + lane];
         }
         const int after_gru = GRAPH ? W.g_hid.heads : first_off;
         pre = gru<4>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? W.gru[1].nh.w[0] : after_gru);

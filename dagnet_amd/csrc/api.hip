@@ -854,8 +854,10 @@ static void fill_common(DnParams &P, const dagnet_model *m, const dagnet_plan *p
 extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_h0, const float *d_x0,
                              const int32_t *d_g0, const float *d_eps, const float *d_q, const int32_t *d_force_goals, uint64_t seed,
                              float *d_out, int32_t *d_out_goals, void *stream) {
-    if (!m || !p || !d_h0 || !d_out) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (!m || !p) return fail(DAGNET_ERR_INVALID, "null argument");
     if (T < 0) return fail(DAGNET_ERR_INVALID, "T must be >= 0");
+    if (T == 0) return DAGNET_OK;          // nothing to roll out (the output tensor is empty)
+    if (!d_h0 || !d_out) return fail(DAGNET_ERR_INVALID, "null argument");
     if (m->dims.model == DAGNET_MODEL_GRAPH) return fail(DAGNET_ERR_INVALID, "stand-alone graph modules have no sample()");
     if (m->dims.model != DAGNET_MODEL_VRNN && !d_x0) return fail(DAGNET_ERR_INVALID, "x_abs_start is required for graph models");
     if (m->dims.model == DAGNET_MODEL_DAGNET && !d_g0) return fail(DAGNET_ERR_INVALID, "g_start is required for DAG-Net");

@@ -33,14 +33,14 @@ def rollout_best_of_k(model, args, batch, num_samples, seed=None):
     if isinstance(model, DAGNet):
         adj = _obs_adjacency(args, seq_start_end, obs_traj, pred_traj_gt)
         goals = obs_goals.to(torch.int32)
-        _, _, _, h = model(obs_traj, obs_traj_rel, goals, seq_start_end, adj)
+        _, _, _, h = model(obs_traj, obs_traj_rel, goals, seq_start_end, adj, seed=seed)
         samples = model.sample_k(num_samples, args.pred_len, h, obs_traj[-1], goals[-1], seq_start_end, seed=seed)
     elif isinstance(model, AVRNN):
         adj = _obs_adjacency(args, seq_start_end, obs_traj, pred_traj_gt)
-        _, _, h = model(obs_traj_rel, adj, seq_start_end=seq_start_end)
+        _, _, h = model(obs_traj_rel, adj, seq_start_end=seq_start_end, seed=seed)
         samples = model.sample_k(num_samples, args.pred_len, h, obs_traj[-1], seq_start_end, seed=seed)
     elif isinstance(model, VRNN):
-        _, _, h = model(obs_traj_rel)
+        _, _, h = model(obs_traj_rel, seed=seed)
         samples = model.sample_k(num_samples, args.pred_len, h, seed=seed)
     else:
         raise TypeError(f"unsupported model {type(model).__name__}")
@@ -69,9 +69,13 @@ def evaluate(args, model, loader, num_samples, seed=None):
         tot[0] += r["ade_sum"]
         tot[1] += r["fde_sum"]
         tot[2] += r["n_agents"]
+    return finalize_metrics(tot, args.pred_len)
+
+
+def finalize_metrics(tot, pred_len):
+    """tot = fp64 [ade_sum, fde_sum, n_agents] of this rank's scenes -> (ADE, FDE) over all ranks.
+    With torch.distributed initialised this is the path's single collective (RCCL all-reduce of 24 bytes)."""
     if torch.distributed.is_available() and torch.distributed.is_initialized():
-        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)   # the single collective
+        torch.distributed.all_reduce(tot, op=torch.distributed.ReduceOp.SUM)
     tot = tot.cpu()
-    ade = float(tot[0] / (tot[2] * args.pred_len))
-    fde = float(tot[1] / tot[2])
-    return ade, fde
+    return float(tot[0] / (tot[2] * pred_len)), float(tot[1] / tot[2])

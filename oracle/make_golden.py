@@ -166,14 +166,9 @@ def _ref_obs_adj(args, sse, obs, gt):
 
 
 def _ref_evaluate_helper(error, sse):
-    # models/dagnet/evaluate_bsk.py:71-82 cannot be imported without running its argparse at import
-    # time on this process's argv; it is 8 lines, re-issued here against the reference's own utils
-    # and cross-checked below against the imported function when the import is possible.
-    err = torch.stack(error, dim=1)
-    tot = 0
-    for (s, e) in sse:
-        tot = tot + torch.min(torch.sum(err[s.item():e.item()], dim=0))
-    return float(tot)
+    """The reference's own evaluate_helper (models/dagnet/evaluate_bsk.py:71-82)."""
+    from models.dagnet.evaluate_bsk import evaluate_helper      # import only builds an argparse parser
+    return float(evaluate_helper(list(error), sse))
 
 
 def graph_case(name, kind, nin, nhid, nout, sizes, seed, nheads=4, alpha=0.2):
@@ -201,12 +196,25 @@ def graph_case(name, kind, nin, nhid, nout, sizes, seed, nheads=4, alpha=0.2):
     print(f"{name}: out {outs['out1'].shape}")
 
 
+def state_dict_layouts():
+    """Key names and shapes of the reference modules' state dicts (the drop-in contract)."""
+    out = {}
+    for tag, kw in (("real_gat", dict(REAL, n_layers=2)), ("real_gcn", dict(REAL, n_layers=1, graph_model="gcn"))):
+        a = syn.make_args(**kw)
+        for name, mod in (("vrnn", RefVRNN(a)), ("avrnn", RefAVRNN(a)), ("dagnet", RefDAGNet(a, 10))):
+            out[f"{name}_{tag}"] = {k: list(v.shape) for k, v in mod.state_dict().items()}
+    with open(os.path.join(OUT, "state_dict_layouts.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("state_dict_layouts.json:", {k: len(v) for k, v in out.items()})
+
+
 TINY = dict(h_dim=16, z_dim=8, rnn_dim=16, g_dim=12)
 REAL = dict(h_dim=64, z_dim=32, rnn_dim=64, g_dim=90)
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
+    state_dict_layouts()
     # --- tiny dims, ragged scenes, every graph x adjacency combination
     for L in (1, 2):
         build_case(f"vrnn_tiny_L{L}", "vrnn", dict(TINY, n_layers=L), [2, 5, 3], 4, 5, 10 + L, 2)
@@ -225,6 +233,9 @@ def main():
     # --- SDD-shaped: obs 8 / pred 12, ragged, z=16 (shipped A-VRNN/VRNN SDD checkpoints)
     build_case("avrnn_sdd_gat", "avrnn", dict(REAL, z_dim=16, n_layers=1), [2, 7, 4, 12], 8, 12, 47, 2, data_kind="sdd")
     build_case("vrnn_sdd", "vrnn", dict(REAL, z_dim=16, n_layers=2), [2, 7, 4], 8, 12, 48, 2, data_kind="sdd")
+    # --- edge cases: a one-agent scene, a 32-agent scene (largest register-resident tile), a 33-agent scene
+    build_case("dagnet_bsk_gat_ragged_1_32", "dagnet", dict(REAL, n_layers=2), [1, 32, 7], 4, 6, 49, 2, data_kind="sdd", g_cells=(9, 10))
+    build_case("avrnn_bsk_gat_n33", "avrnn", dict(REAL, n_layers=1), [33, 2], 4, 5, 50, 1, data_kind="sdd")
     # --- stand-alone graph modules
     graph_case("gat_hid", "gat", 64, 8, 64, [2, 5, 3, 10], 51)
     graph_case("gat_goal", "gat", 90, 8, 90, [3, 10], 52)

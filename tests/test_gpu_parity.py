@@ -61,12 +61,13 @@ def test_sample_matches_reference(name):
     h = torch.from_numpy(gold["fwd_h"]).to(DEV)
     K, T, kind = meta["K"], meta["pred_len"], meta["kind"]
     eps_s = eps_s.to(DEV)
+    k1 = K - 1
     if kind == "vrnn":
         s = model.sample_k(K, T, h, eps=eps_s)
-        s1 = model.sample(T, h, eps=eps_s[1])
+        s1 = model.sample(T, h, eps=eps_s[k1])
     elif kind == "avrnn":
         s = model.sample_k(K, T, h, obs[-1].to(DEV), sse, eps=eps_s)
-        s1 = model.sample(T, h, obs[-1].to(DEV), sse, eps=eps_s[1])
+        s1 = model.sample(T, h, obs[-1].to(DEV), sse, eps=eps_s[k1])
     else:
         g0 = obs_goals[-1].to(DEV).to(torch.int32)
         s, goals = model.sample_k(K, T, h, obs[-1].to(DEV), g0, sse, eps=eps_s, q=q_s.to(DEV), return_goals=True)
@@ -74,12 +75,12 @@ def test_sample_matches_reference(name):
         assert np.array_equal(goals.cpu().numpy(), gold["goals"]), "sampled goals differ from the reference"
         from dagnet_amd.utils import to_goals_one_hot
         s1 = model.sample(T, h, obs[-1].to(DEV), to_goals_one_hot(obs_goals, args.g_dim)[-1].to(DEV), sse,
-                          eps=eps_s[1], q=q_s[1].to(DEV))
+                          eps=eps_s[k1], q=q_s[k1].to(DEV))
     assert s.shape == gold["samples"].shape
     _close(s.cpu(), gold["samples"], DISP_ATOL, DISP_RTOL, "samples")
     # the reference-signature single-sample call is the K=1 slice of the batched launch (a scene may sit
     # at another position of its tile, which reorders the attention sums: equal to rounding, not bitwise)
-    _close(s1.cpu(), s[1].cpu(), 2e-6, 1e-5, "sample() vs sample_k()[1]")
+    _close(s1.cpu(), s[k1].cpu(), 2e-6, 1e-5, "sample() vs sample_k()[K-1]")
     # metrics (relative_to_abs + ADE/FDE raw + min-over-K per scene)
     from dagnet_amd import _capi
     from dagnet_amd._runtime import scene_ptr_from_sse

@@ -1,0 +1,256 @@
+"""GPU: properties that hold at any size (full BASELINE sizes included), agreement between the two rollout
+kernels, the oracle on larger seeded inputs, edge cases and error behaviour -- all through the C ABI."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import dagnet_amd
+from dagnet_amd import _capi, synthetic as syn
+from dagnet_amd._runtime import scene_ptr_from_sse
+from oracle import dagnet_oracle as orc
+from tests.cases import DISP_ATOL, DISP_RTOL
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(kind, n_max=10, seed=7, **kw):
+    a = syn.make_args(**kw)
+    m = {"vrnn": lambda: dagnet_amd.VRNN(a), "avrnn": lambda: dagnet_amd.AVRNN(a), "dagnet": lambda: dagnet_amd.DAGNet(a, n_max)}[kind]()
+    sd = syn.random_state_dict(m, seed)
+    m.load_state_dict(sd)
+    return a, m.to(DEV).eval(), sd
+
+
+def _sample_k(kind, m, K, T, h, batch, **kw):
+    obs, gt, obs_rel, gt_rel, og, pg, sse = batch
+    if kind == "vrnn":
+        kw.pop("q", None)
+        return m.sample_k(K, T, h, **kw)
+    if kind == "avrnn":
+        kw.pop("q", None)
+        return m.sample_k(K, T, h, obs[-1], sse, **kw)
+    return m.sample_k(K, T, h, obs[-1], og[-1].to(torch.int32), sse, **kw)
+
+
+class generic_kernel:
+    """Force the LDS-tiled generic kernel (rollout.hip) instead of the register-resident one."""
+
+    def __enter__(self):
+        os.environ["DAGNET_FORCE_GENERIC"] = "1"
+
+    def __exit__(self, *a):
+        del os.environ["DAGNET_FORCE_GENERIC"]
+
+
+@pytest.mark.parametrize("kind,kw", [("vrnn", dict(n_layers=2)), ("avrnn", dict(n_layers=1)), ("dagnet", dict(n_layers=2))])
+def test_both_kernels_agree_and_are_deterministic(kind, kw):
+    """Same seed -> the register-resident and the generic kernel draw the same Philox numbers; trajectories agree to
+    fp32 reordering noise, goal indices exactly; a second launch is bitwise identical; another seed differs."""
+    a, m, _ = _model(kind, **kw)
+    sizes = [10] * 37
+    batch = [t.to(DEV) for t in syn.make_batch(sizes, 10, 40, 3)]
+    h = (syn.uniform_noise(3, "h0", (a.n_layers, 370, 64)) - 0.5).to(DEV)
+    extra = dict(return_goals=True) if kind == "dagnet" else {}
+    r1 = _sample_k(kind, m, 4, 40, h, batch, seed=11, **extra)
+    r2 = _sample_k(kind, m, 4, 40, h, batch, seed=11, **extra)
+    r3 = _sample_k(kind, m, 4, 40, h, batch, seed=12, **extra)
+    with generic_kernel():
+        g1 = _sample_k(kind, m, 4, 40, h, batch, seed=11, **extra)
+    if kind == "dagnet":
+        (r1, q1), (r2, q2), (r3, q3), (g1, gq1) = r1, r2, r3, g1
+        assert torch.equal(q1, q2)
+        agree = (q1 == gq1).float().mean().item()
+        assert agree > 0.999, f"goal draws of the two kernels agree on only {agree:.4f} of the rows"
+        same = (q1 == gq1).all(dim=1)                      # [K,N]: rows whose whole goal sequence agrees
+        d = (r1 - g1).abs().amax(dim=(1, 3))
+        assert d[same].max().item() < 1e-3                 # chaotic amplification over 40 steps of ~1e-6 noise
+    else:
+        assert (r1 - g1).abs().max().item() < 2e-4
+    assert torch.equal(r1, r2)
+    assert not torch.equal(r1, r3)
+    assert torch.isfinite(r1).all()
+
+
+@pytest.mark.parametrize("kind", ["vrnn", "avrnn", "dagnet"])
+@pytest.mark.parametrize("force_generic", [False, True])
+def test_matches_oracle_on_larger_ragged_batch(kind, force_generic):
+    """48 ragged scenes (1..32 agents), injected noise, goals forced to the oracle's draws so that the continuous
+    path is compared row by row; the categorical draw itself is compared where its top-2 margin is safe."""
+    kw = dict(vrnn=dict(n_layers=2), avrnn=dict(n_layers=1), dagnet=dict(n_layers=2))[kind]
+    sizes = [1, 32, 2, 17] + list(syn.ragged_sizes(44, seed=5, n_max=16))
+    nmax = max(sizes)
+    a, m, sd = _model(kind, n_max=16 if kind == "dagnet" and nmax <= 16 else nmax, **kw)
+    T, K, seed = 12, 2, 21
+    batch = syn.make_batch(sizes, 8, T, seed, kind="sdd", g_cells=(9, 10))
+    obs, gt, obs_rel, gt_rel, og, pg, sse = batch
+    N = obs.shape[1]
+    h = syn.uniform_noise(seed, "h0", (a.n_layers, N, 64)) - 0.5
+    eps = syn.uniform_noise(seed, "eps", (K, T, N, a.z_dim))
+    q = syn.exp1_noise(seed, "q", (K, T, N, a.g_dim))
+    cfg = orc.make_cfg(n_max_agents=m.n_max_agents if kind == "dagnet" else nmax, n_layers=a.n_layers)
+    want, wgoals, margins = [], [], []
+    with torch.no_grad():
+        for k in range(K):
+            if kind == "vrnn":
+                want.append(orc.vrnn_sample(sd, cfg, T, h, eps[k]))
+            elif kind == "avrnn":
+                want.append(orc.avrnn_sample(sd, cfg, T, h, obs[-1], sse, eps[k]))
+            else:
+                tr = []
+                want.append(orc.dagnet_sample(sd, cfg, T, h, obs[-1], orc.one_hot(og[-1], a.g_dim), sse, eps[k], q[k], trace=tr))
+                wgoals.append(torch.stack([t["goal"] for t in tr]))
+                margins.append(torch.stack([t["margin"] for t in tr]))
+    want = torch.stack(want)
+    dbatch = [t.to(DEV) for t in batch]
+    ctx = generic_kernel() if force_generic else __import__("contextlib").nullcontext()
+    with ctx:
+        if kind == "dagnet":
+            wg = torch.stack(wgoals).to(torch.int32)
+            got = _sample_k(kind, m, K, T, h.to(DEV), dbatch, eps=eps.to(DEV), q=q.to(DEV), force_goals=wg.to(DEV))
+            free, goals = _sample_k(kind, m, K, T, h.to(DEV), dbatch, eps=eps.to(DEV), q=q.to(DEV), return_goals=True)
+            # first step: identical inputs -> the draw must agree wherever the oracle's top-2 margin is safe
+            safe = torch.stack(margins)[:, 0] > 1e-4
+            assert torch.equal(goals.cpu()[:, 0][safe], wg[:, 0][safe])
+        else:
+            got = _sample_k(kind, m, K, T, h.to(DEV), dbatch, eps=eps.to(DEV))
+    err = (got.cpu() - want).abs() - (DISP_ATOL + DISP_RTOL * want.abs())
+    assert err.max().item() <= 0, f"max abs diff {(got.cpu() - want).abs().max().item():.3e}"
+
+
+def test_samples_are_independent_of_batch_composition():
+    """A scene rolled out alone equals the same scene inside a batch (block-diagonal attention is exact)."""
+    a, m, _ = _model("dagnet", n_layers=2)
+    sizes = [10, 4, 10, 7]
+    batch = syn.make_batch(sizes, 10, 20, 9)
+    obs, gt, obs_rel, gt_rel, og, pg, sse = batch
+    N = obs.shape[1]
+    h = syn.uniform_noise(9, "h0", (2, N, 64)) - 0.5
+    eps = syn.uniform_noise(9, "eps", (1, 20, N, 32))
+    q = syn.exp1_noise(9, "q", (1, 20, N, 90))
+    full = m.sample_k(1, 20, h.to(DEV), obs[-1].to(DEV), og[-1].to(DEV).to(torch.int32), sse, eps=eps.to(DEV), q=q.to(DEV))
+    lo, hi = 14, 24      # third scene
+    alone = m.sample_k(1, 20, h[:, lo:hi].contiguous().to(DEV), obs[-1, lo:hi].to(DEV), og[-1, lo:hi].to(DEV).to(torch.int32),
+                       torch.tensor([[0, 10]]), eps=eps[:, :, lo:hi].contiguous().to(DEV), q=q[:, :, lo:hi].contiguous().to(DEV))
+    assert (full[:, :, lo:hi] - alone).abs().max().item() < 2e-5
+
+
+def test_adjacency_underflow_threshold():
+    """exp(-d/sigma) underflows to 0 in fp32 beyond d ~ 103.97 sigma: both kernels and the adjacency op must cut
+    exactly where the reference's fp64->fp32 cast does."""
+    from dagnet_amd.adjacency_matrix import adjs_distance_sim_pred
+    sigma = 1.2
+    lim = 150 * np.log(2.0) * sigma
+    d = np.array([0.0, lim - 1e-3, lim + 1e-3, lim * 0.5, lim * 2], dtype=np.float32)
+    pos = torch.tensor(np.stack([d, np.zeros_like(d)], 1))
+    sse = torch.tensor([[0, 5]])
+    want = orc.adj_distance_sim(sigma, sse, pos)
+    got = adjs_distance_sim_pred(sigma, sse, pos.to(DEV)).cpu()
+    assert torch.equal(got > 0, want > 0) and (want[0] > 0).tolist() == [True, True, False, True, False]
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-6, atol=0)
+    a, m, sd = _model("avrnn", n_layers=1)
+    h = syn.uniform_noise(1, "h0", (1, 5, 64)) - 0.5
+    eps = syn.uniform_noise(1, "eps", (1, 3, 5, 32))
+    cfg = orc.make_cfg(n_layers=1)
+    with torch.no_grad():
+        ref = orc.avrnn_sample(sd, cfg, 3, h, pos, sse, eps[0])
+    for ctx in (generic_kernel(), __import__("contextlib").nullcontext()):
+        with ctx:
+            got = m.sample_k(1, 3, h.to(DEV), pos.to(DEV), sse, eps=eps.to(DEV))[0].cpu()
+        assert (got - ref).abs().max().item() < 1e-5
+
+
+def test_best_of_k_at_full_size_is_consistent():
+    """BASELINE config 3 size (4096 scenes x 10 agents x K=20 x T=40): the fused metric kernels agree with a
+    re-derivation from their own raw outputs, and with a sharded (2-way) evaluation of the same trajectories."""
+    a, m, _ = _model("dagnet", n_layers=2)
+    S, n, K, T = 4096, 10, 20, 40
+    batch = [t.to(DEV) for t in syn.make_batch([n] * S, 10, T, 1)]
+    obs, gt, obs_rel, gt_rel, og, pg, sse = batch
+    h = (torch.rand(2, S * n, 64, device=DEV) - 0.5)
+    s = m.sample_k(K, T, h, obs[-1], og[-1].to(torch.int32), sse, seed=5)
+    assert s.shape == (K, T, S * n, 2) and torch.isfinite(s).all()
+    plan = _capi.HipPlan(None, scene_ptr_from_sse(sse), 1, device=DEV)
+    r = _capi.best_of_k(plan, s, obs[-1].contiguous(), gt)
+    # re-derive from the raw per-agent errors (torch on device is only the checker here)
+    ade_scene = r["ade_raw"].view(K, S, n).sum(2).min(0).values.double().sum()
+    fde_scene = r["fde_raw"].view(K, S, n).sum(2).min(0).values.double().sum()
+    assert abs(ade_scene.item() - r["sums"][0].item()) < 1e-6 * ade_scene.item()
+    assert abs(fde_scene.item() - r["sums"][1].item()) < 1e-6 * fde_scene.item()
+    absd = torch.cumsum(s[3], 0) + obs[-1][None]
+    ade3 = torch.sqrt(((gt - absd) ** 2).sum(2)).sum(0)
+    assert (ade3 - r["ade_raw"][3]).abs().max().item() < 1e-2 and (ade3 - r["ade_raw"][3]).abs().mean().item() < 1e-4
+    # two shards of the scenes, evaluated independently, add up to the whole
+    half = S // 2 * n
+    tot = torch.zeros(2, dtype=torch.float64)
+    for lo, hi in ((0, half), (half, S * n)):
+        sp = _capi.HipPlan(None, np.arange(0, hi - lo + 1, n, dtype=np.int32), 1, device=DEV)
+        rr = _capi.best_of_k(sp, s[:, :, lo:hi].contiguous(), obs[-1, lo:hi].contiguous(), gt[:, lo:hi].contiguous())
+        tot += rr["sums"].cpu()
+    assert torch.allclose(tot, r["sums"].cpu(), rtol=1e-12)
+
+
+def test_utils_match_oracle():
+    from dagnet_amd import utils
+    rel = torch.randn(12, 33, 2)
+    start = torch.randn(33, 2) * 10
+    gt = torch.randn(12, 33, 2) * 3
+    a = utils.relative_to_abs(rel.to(DEV), start.to(DEV))
+    assert (a.cpu() - orc.relative_to_abs(rel, start)).abs().max().item() < 1e-5
+    ade = utils.average_displacement_error(a, gt.to(DEV), mode="raw")
+    fde = utils.final_displacement_error(a[-1], gt[-1].to(DEV), mode="raw")
+    np.testing.assert_allclose(ade.cpu().numpy(), orc.ade_raw(a.cpu(), gt).numpy(), rtol=1e-5)
+    np.testing.assert_allclose(fde.cpu().numpy(), orc.fde_raw(a.cpu()[-1], gt[-1]).numpy(), rtol=1e-5)
+    assert abs(utils.average_displacement_error(a, gt.to(DEV)).item() - orc.ade_raw(a.cpu(), gt).sum().item()) < 1e-2
+    w = torch.rand(50, 90) + 0.01
+    q = syn.exp1_noise(3, "q", (50, 90))
+    oh = utils.sample_multinomial(w.to(DEV), q=q.to(DEV))
+    assert torch.equal(oh.argmax(1).cpu(), orc.sample_goal(w, q)) and oh.sum().item() == 50
+    ohe = utils.to_goals_one_hot(torch.tensor([[1.0, 3.0], [0.0, 2.0]]), 4)
+    assert ohe.shape == (2, 2, 4) and ohe[0, 1, 3] == 1 and ohe.sum() == 4
+    from dagnet_amd.evaluate import evaluate_helper
+    errs = [torch.rand(10, device=DEV) for _ in range(4)]
+    sse = torch.tensor([[0, 3], [3, 10]])
+    want = orc.min_over_k_sum(torch.stack([e.cpu() for e in errs]), sse)
+    assert abs(evaluate_helper(errs, sse).item() - want.item()) < 1e-5
+
+
+def test_evaluate_end_to_end():
+    """evaluate() over a 2-batch loader = forward + K rollouts + min-over-K metrics, per the reference's formulae."""
+    from dagnet_amd.evaluate import evaluate, rollout_best_of_k
+    a, m, _ = _model("dagnet", n_layers=2)
+    loader = [syn.make_batch([10] * 5, 10, 40, s) for s in (1, 2)]
+    ade, fde = evaluate(a, m, loader, num_samples=20, seed=3)
+    tot = np.zeros(3)
+    for b in loader:
+        r = rollout_best_of_k(m, a, [t.to(DEV) for t in b], 20, seed=3)
+        tot += [r["ade_sum"].item(), r["fde_sum"].item(), r["n_agents"]]
+    assert abs(ade - tot[0] / (tot[2] * 40)) < 1e-9 and abs(fde - tot[1] / tot[2]) < 1e-9 and np.isfinite([ade, fde]).all()
+    for kind, kw in (("avrnn", dict(n_layers=1)), ("vrnn", dict(n_layers=2))):
+        a2, m2, _ = _model(kind, **kw)
+        ade2, fde2 = evaluate(a2, m2, loader, num_samples=5, seed=3)
+        assert np.isfinite([ade2, fde2]).all() and ade2 > 0
+
+
+def test_errors_are_loud():
+    a, m, _ = _model("dagnet", n_layers=2)
+    sse = torch.tensor([[0, 4]])
+    h = torch.zeros(2, 4, 64, device=DEV)
+    x0 = torch.zeros(4, 2, device=DEV)
+    g0 = torch.zeros(4, dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError, match="covers 4 rows"):
+        m.sample_k(1, 3, h[:, :3].contiguous(), x0, g0, sse)
+    with pytest.raises(_capi.DagnetHipError, match=r"h must be"):
+        m.sample_k(1, 3, h[:1].contiguous(), x0, g0, sse)
+    with pytest.raises(_capi.DagnetHipError, match=r"x_abs_start must be"):
+        m.sample_k(1, 3, h, x0[:3].contiguous(), g0, sse)
+    with pytest.raises(_capi.DagnetHipError, match="eps must be"):
+        m.sample_k(1, 3, h, x0, g0, sse, eps=torch.zeros(1, 3, 4, 31, device=DEV))
+    with pytest.raises(ValueError):
+        m.sample_k(1, 3, h, x0, g0, torch.tensor([[0, 3]]))
+    a5, m5, _ = _model("dagnet", n_max=3, n_layers=2)
+    with pytest.raises(_capi.DagnetHipError, match="n_max_agents"):
+        m5.sample_k(1, 3, h, x0, g0, sse)
+    assert m.sample_k(2, 0, h, x0, g0, sse).shape == (2, 0, 4, 2)

@@ -37,6 +37,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 dn_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ float dn_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 
+#ifndef DN_V2_DEPTH
+#define DN_V2_DEPTH 1     // weight blocks in flight ahead of the MFMAs (1 block = 16 MFMAs = 1024 cycles of cover)
+#endif
+
 namespace v2 {
 
 // All weight traffic goes through ONE buffer descriptor (4 SGPRs): per-lane part of the address is a
@@ -103,11 +107,19 @@ template <int NT, int KT, bool TR>
 __device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, const T16 (&x)[KT], int lane, WBlk pre,
                                    int next_off) {
     constexpr int NB = NT * KT;
+#if DN_V2_DEPTH == 2
     WBlk q0 = pre, q1, q2;
     q1 = wload(wp, NB > 1 ? off + 1024 : next_off, lane);
+#else
+    WBlk q0 = pre, q1;
+#endif
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
+#if DN_V2_DEPTH == 2
         if (b + 2 <= NB) q2 = wload(wp, b + 2 < NB ? off + (b + 2) * 1024 : next_off, lane);
+#else
+        q1 = wload(wp, b + 1 < NB ? off + (b + 1) * 1024 : next_off, lane);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         const int nt = b / KT, kt = b % KT;
 #pragma unroll
@@ -127,7 +139,9 @@ __device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, cons
         }
         __builtin_amdgcn_sched_barrier(0);
         q0 = q1;
+#if DN_V2_DEPTH == 2
         q1 = q2;
+#endif
     }
     return q0;
 }

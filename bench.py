@@ -33,6 +33,9 @@ WORKLOADS = {
     "dagnet_bsk_4096x20": dict(kind="dagnet", scenes=4096, agents=10, K=20, obs=10, pred=40, args=dict(n_layers=2)),
     # configs[1]: A-VRNN (single GAT on hidden states), 512 scenes
     "avrnn_bsk_512x20": dict(kind="avrnn", scenes=512, agents=10, K=20, obs=10, pred=40, args=dict(n_layers=1)),
+    # configs[3]: DAG-Net SDD-shaped: obs 8 / pred 12, ragged scenes (2..32 agents, mean 6), g_dim = 32 x 30 = 960
+    "dagnet_sdd_1024x20": dict(kind="dagnet", scenes=1024, agents=0, K=20, obs=8, pred=12, args=dict(n_layers=2, g_dim=960),
+                               data="sdd", g_cells=(32, 30)),
     # configs[0] shape on the GPU: VRNN baseline
     "vrnn_bsk_4096x20": dict(kind="vrnn", scenes=4096, agents=10, K=20, obs=10, pred=40, args=dict(n_layers=2)),
 }
@@ -58,10 +61,16 @@ def flops_per_row_step(kind, a, n, d_dim):
     return 2 * mac
 
 
+def scene_sizes(wl, seed=0):
+    if wl["agents"]:
+        return [wl["agents"]] * wl["scenes"]
+    return [int(v) for v in syn.ragged_sizes(wl["scenes"], seed=seed)]
+
+
 def build(wl, device, seed=0):
     a = syn.make_args(obs_len=wl["obs"], pred_len=wl["pred"], **wl["args"])
     if wl["kind"] == "dagnet":
-        model = dagnet_amd.DAGNet(a, wl["agents"])
+        model = dagnet_amd.DAGNet(a, wl["agents"] or 32)
     elif wl["kind"] == "avrnn":
         model = dagnet_amd.AVRNN(a)
     else:
@@ -77,15 +86,16 @@ def cpu_baseline(wl, budget_s=20.0):
     from oracle import dagnet_oracle as orc
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
     cores = torch.get_num_threads()
-    scenes, n, T = 32, wl["agents"], wl["pred"]
+    scenes, n, T = 32, wl["agents"] or 6, wl["pred"]
     a = syn.make_args(obs_len=wl["obs"], pred_len=T, **wl["args"])
     kind = wl["kind"]
-    ref_mod = {"dagnet": lambda: dagnet_amd.DAGNet(a, n), "avrnn": lambda: dagnet_amd.AVRNN(a), "vrnn": lambda: dagnet_amd.VRNN(a)}[kind]()
+    ref_mod = {"dagnet": lambda: dagnet_amd.DAGNet(a, wl["agents"] or 32), "avrnn": lambda: dagnet_amd.AVRNN(a), "vrnn": lambda: dagnet_amd.VRNN(a)}[kind]()
     sd = syn.random_state_dict(ref_mod, 128)
-    cfg = orc.make_cfg(n_max_agents=n, **{k: getattr(a, k) for k in ("x_dim", "h_dim", "z_dim", "rnn_dim", "n_layers", "g_dim",
+    cfg = orc.make_cfg(n_max_agents=wl["agents"] or 32, **{k: getattr(a, k) for k in ("x_dim", "h_dim", "z_dim", "rnn_dim", "n_layers", "g_dim",
                                                                       "graph_model", "graph_hid", "adjacency_type",
                                                                       "top_k_neigh", "sigma", "alpha", "n_heads")})
-    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = syn.make_batch([n] * scenes, wl["obs"], T, 1)
+    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = syn.make_batch([n] * scenes, wl["obs"], T, 1, kind=wl.get("data", "bsk"),
+                                                                        g_cells=wl.get("g_cells", (9, 10)))
     N = obs.shape[1]
     h = syn.uniform_noise(1, "h0", (a.n_layers, N, a.rnn_dim)) - 0.5
 
@@ -134,9 +144,13 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     a, model = build(wl, dev)
-    S, n, K, T = wl["scenes"], wl["agents"], wl["K"], wl["pred"]
+    S, K, T = wl["scenes"], wl["K"], wl["pred"]
+    sizes = scene_sizes(wl, seed=rank)
+    n_rows = int(sum(sizes))
+    n = n_rows / S                      # agents per scene (mean, for ragged workloads)
     # weak scaling: every rank owns S scenes of its own (seeded by rank)
-    batch = [t.to(dev) for t in syn.make_batch([n] * S, wl["obs"], T, 1000 + rank)]
+    batch = [t.to(dev) for t in syn.make_batch(sizes, wl["obs"], T, 1000 + rank, kind=wl.get("data", "bsk"),
+                                               g_cells=wl.get("g_cells", (9, 10)))]
     obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = batch
     from dagnet_amd.evaluate import _obs_adjacency
     goals = obs_goals.to(torch.int32)
@@ -168,7 +182,7 @@ def main():
         if timed:
             ev[i][1].record()
         r = _capi.best_of_k(metric_plan, s, x0, gt)
-        tot = torch.cat([r["sums"], torch.tensor([float(S * n)], dtype=torch.float64, device=dev)])
+        tot = torch.cat([r["sums"], torch.tensor([float(n_rows)], dtype=torch.float64, device=dev)])
         if dist is not None:
             dist.all_reduce(tot)
         return tot
@@ -191,12 +205,16 @@ def main():
         dt = float(tmax.item())
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in ev])) if opt.steps else float("nan")
     tot = tot.cpu()
-    traj_per_step = S * n * K * world
+    traj_local = torch.tensor([float(n_rows * K)], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(traj_local)
+    traj_per_step = float(traj_local.item())
     value = traj_per_step * opt.steps / dt
 
     if rank == 0:
-        fl = flops_per_row_step(wl["kind"], a, n, 2 * n) * T          # FLOP per sampled trajectory
-        launch_flop = fl * S * n * K                                   # one launch = this rank's rows
+        d_dim = 2 * (wl["agents"] or 32)
+        launch_flop = float(sum(flops_per_row_step(wl["kind"], a, ns, d_dim) * ns for ns in sizes)) * T * K   # this rank's rows
+        fl = launch_flop / (n_rows * K)                                # FLOP per sampled trajectory (mean)
         achieved = launch_flop / (kernel_ms * 1e-3) / 1e12
         info = model.hip_plan(dev, sp, K).info()
         line = {
@@ -204,12 +222,12 @@ def main():
             "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": opt.workload, "model": wl["kind"], "scenes_per_gpu": S, "agents_per_scene": n,
-                       "samples": K, "obs_len": wl["obs"], "pred_len": T, "rows_per_gpu": S * n * K,
+                       "samples": K, "obs_len": wl["obs"], "pred_len": T, "rows_per_gpu": n_rows * K,
                        "tile_rows": info["tile_rows"], "tiles": info["n_tiles"], "lds_bytes": info["lds_bytes"],
                        "parallelism": f"scenes sharded x{world}, 1 all-reduce of 3 doubles per step"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
-                         "kernel": "dagnet_rollout_kernel<sample>", "kernel_ms": kernel_ms,
+                         "kernel": info["sample_kernel"], "kernel_ms": kernel_ms,
                          "flop_per_trajectory": fl},
             "forward_obs_ms": fwd_ms,
             "ade": float(tot[0] / (tot[2] * T)), "fde": float(tot[1] / tot[2]),

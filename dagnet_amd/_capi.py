@@ -23,7 +23,7 @@ GRAPH_NONE, GRAPH_GAT, GRAPH_GCN = 0, 1, 2
 # every symbol include/dagnet_hip.h declares (tests check the .so exports all of them)
 EXPORTS = (
     "dagnet_last_error", "dagnet_version", "dagnet_model_create", "dagnet_model_destroy",
-    "dagnet_plan_create", "dagnet_plan_destroy", "dagnet_plan_info", "dagnet_sample", "dagnet_forward",
+    "dagnet_plan_create", "dagnet_plan_destroy", "dagnet_plan_info", "dagnet_plan_kernel", "dagnet_sample", "dagnet_forward",
     "dagnet_graph_forward", "dagnet_adjacency", "dagnet_plan_compact_adj_size", "dagnet_best_of_k",
     "dagnet_relative_to_abs", "dagnet_categorical", "dagnet_displacement_errors", "dagnet_scene_min_sum",
 )
@@ -69,6 +69,7 @@ def load():
         lib.dagnet_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         lib.dagnet_plan_destroy.argtypes = [C.c_void_p]
         lib.dagnet_plan_destroy.restype = None
+        lib.dagnet_plan_kernel.argtypes = [C.c_void_p]
         lib.dagnet_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
         vp = C.c_void_p
         lib.dagnet_sample.argtypes = [vp, vp, C.c_int32, vp, vp, vp, vp, vp, vp, C.c_uint64, vp, vp, vp]
@@ -161,7 +162,9 @@ class HipPlan:
     def info(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int64()
         _check(load().dagnet_plan_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return dict(tile_rows=a.value, n_tiles=b.value, lds_bytes=c.value)
+        kern = {2: "rollout_v2_kernel (register-resident)", 1: "dagnet_rollout_big_kernel (generic, goal buffers in global scratch)",
+                0: "dagnet_rollout_kernel (generic, LDS-tiled)"}.get(load().dagnet_plan_kernel(self._h), "none")
+        return dict(tile_rows=a.value, n_tiles=b.value, lds_bytes=c.value, sample_kernel=kern)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None

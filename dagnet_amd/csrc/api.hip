@@ -75,6 +75,11 @@ struct dagnet_plan {
     // 32-row tiles for the register-resident kernel (only when the model and every scene qualify)
     int32_t *d_tile2_u0 = nullptr, *d_tile2_nu = nullptr;
     int n_tiles2 = 0;
+    // big-G plans (rollout_body.h with DN_BIG): per-workgroup global slabs for the goal-width buffers
+    bool big = false;
+    float *d_gscratch = nullptr;
+    int64_t gslab = 0;
+    int gblocks = 0;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -636,7 +641,8 @@ extern "C" void dagnet_model_destroy(dagnet_model *m) {
 }
 
 // LDS layout for tile height M; returns total floats
-static DnLds make_layout(const DnDims &D, int M, int AS) {
+// big: the three goal-width buffers get offsets >= total, i.e. they live in the workgroup's global slab
+static DnLds make_layout(const DnDims &D, int M, int AS, bool big = false) {
     DnLds L;
     memset(&L, 0, sizeof(L));
     L.M = M;
@@ -672,7 +678,7 @@ static DnLds make_layout(const DnDims &D, int M, int AS) {
     L.px = u0 + 2 * TW * M;
     L.pz = L.px + Hp * M;
     int usize = (2 * TW + 2 * Hp) * M;
-    if (dag) {
+    if (dag && !big) {
         const int Gp = pad32(D.G);
         L.decg = u0;
         L.gg = u0 + Gp * M;
@@ -681,6 +687,12 @@ static DnLds make_layout(const DnDims &D, int M, int AS) {
     }
     off += usize;
     L.total = std::max(off, 3 * DN_THREADS * 2);   // room for the fp64 loss reduction at offset 0
+    if (dag && big) {
+        const int Gp = pad32(D.G);
+        L.decg = L.total;
+        L.gg = L.total + Gp * M;
+        L.gcomb = L.total + 2 * Gp * M;
+    }
     return L;
 }
 
@@ -710,6 +722,16 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
         if (cand[i] < nmax) continue;
         L = make_layout(m->dims, cand[i], nmax);
         if ((int64_t)L.total * 4 <= kLdsBudgetBytes) M = cand[i];
+    }
+    bool big = false;
+    if (m && !M && m->dims.model == DAGNET_MODEL_DAGNET) {
+        // goal-width buffers do not fit the LDS (g_dim in the hundreds): keep them in a global slab per workgroup
+        const int cand_big[3] = {64, 32, 128};
+        for (int i = 0; i < 3 && !M; ++i) {
+            if (cand_big[i] < nmax) continue;
+            L = make_layout(m->dims, cand_big[i], nmax, true);
+            if ((int64_t)L.total * 4 <= kLdsBudgetBytes) { M = cand_big[i]; big = true; }
+        }
     }
     if (m && !M)
         return fail(DAGNET_ERR_CAPACITY,
@@ -762,6 +784,7 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
     dagnet_plan *p = new dagnet_plan();
     p->S = S; p->N = N; p->K = K; p->M = M; p->AS = nmax; p->lds = L;
     p->owner = m;
+    p->big = big;
     p->n_tiles = (int)u0.size();
     p->compact_size = acc;
     hipError_t e = hipGetDevice(&p->device);
@@ -784,6 +807,11 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
     up(reinterpret_cast<void **>(&p->d_off_dense), offd.data(), sizeof(int64_t) * S);
     up(reinterpret_cast<void **>(&p->d_off_compact), offc.data(), sizeof(int64_t) * S);
     if (m && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_loss_part), sizeof(double) * 3 * p->n_tiles);
+    if (big && e == hipSuccess) {
+        p->gslab = (int64_t)3 * pad32(m->dims.G) * M;
+        p->gblocks = std::min(p->n_tiles, 1024);
+        e = hipMalloc(reinterpret_cast<void **>(&p->d_gscratch), sizeof(float) * p->gslab * p->gblocks);
+    }
     if (m) {
         DnParams P;
         memset(&P, 0, sizeof(P));
@@ -802,7 +830,7 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
 
 extern "C" void dagnet_plan_destroy(dagnet_plan *p) {
     if (!p) return;
-    void *ptrs[] = {p->d_scene_ptr, p->d_tile_u0, p->d_tile_nu, p->d_row_scene, p->d_off_dense, p->d_off_compact, p->d_loss_part, p->d_static, p->d_tile2_u0, p->d_tile2_nu};
+    void *ptrs[] = {p->d_scene_ptr, p->d_tile_u0, p->d_tile_nu, p->d_row_scene, p->d_off_dense, p->d_off_compact, p->d_loss_part, p->d_static, p->d_tile2_u0, p->d_tile2_nu, p->d_gscratch};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -846,6 +874,9 @@ static void fill_common(DnParams &P, const dagnet_model *m, const dagnet_plan *p
     P.r.N = p->N;
     P.r.K = p->K;
     P.r.n_tiles = p->n_tiles;
+    P.r.gscratch = p->d_gscratch;
+    P.r.gslab = p->gslab;
+    P.r.gblocks = p->gblocks;
 #ifdef DN_PROFILE
     P.r.prof = g_prof;
 #endif
@@ -962,6 +993,12 @@ extern "C" int dagnet_adjacency(const dagnet_plan *p, int32_t adjacency_type, do
     HIP_TRY(dn_launch_adjacency(adjacency_type, sigma, top_k, p->d_scene_ptr, p->d_row_scene, dense_ld ? p->d_off_dense : p->d_off_compact,
                                 p->N, T, d_pos, d_out, dense_ld, tstride, st));
     return DAGNET_OK;
+}
+
+extern "C" int dagnet_plan_kernel(const dagnet_plan *p) {
+    if (!p || !p->owner) return -1;
+    if (p->owner->v2 && p->n_tiles2 > 0 && !getenv("DAGNET_FORCE_GENERIC")) return 2;
+    return p->big ? 1 : 0;
 }
 
 extern "C" int64_t dagnet_plan_compact_adj_size(const dagnet_plan *p) { return p ? p->compact_size : -1; }

@@ -114,6 +114,9 @@ struct DnRun {
     const float *gx;
     float *gout;
     int32_t gwhich;
+    float *gscratch;            // big-G plans: [gblocks][gslab] floats of global scratch, else NULL
+    int64_t gslab;
+    int32_t gblocks;
     long long *prof;            // DN_PROFILE builds: per-phase cycle counters of tile 0 (else unused)
 };
 

@@ -233,6 +233,10 @@ def main():
     # --- SDD-shaped: obs 8 / pred 12, ragged, z=16 (shipped A-VRNN/VRNN SDD checkpoints)
     build_case("avrnn_sdd_gat", "avrnn", dict(REAL, z_dim=16, n_layers=1), [2, 7, 4, 12], 8, 12, 47, 2, data_kind="sdd")
     build_case("vrnn_sdd", "vrnn", dict(REAL, z_dim=16, n_layers=2), [2, 7, 4], 8, 12, 48, 2, data_kind="sdd")
+    # --- SDD-shaped DAG-Net: g_dim = 32 x 30 = 960 (models/dagnet/train_sdd.py:29-30,334), ragged scenes
+    build_case("dagnet_sdd_gat_g960", "dagnet", dict(REAL, g_dim=960, n_layers=2), [2, 7, 4], 8, 12, 55, 2, data_kind="sdd", g_cells=(32, 30))
+    build_case("dagnet_sdd_gcn_g960", "dagnet", dict(REAL, g_dim=960, n_layers=1, graph_model="gcn", adjacency_type=2, top_k_neigh=3), [3, 9], 8, 12, 56, 1,
+               data_kind="sdd", g_cells=(32, 30))
     # --- edge cases: a one-agent scene, a 32-agent scene (largest register-resident tile), a 33-agent scene
     build_case("dagnet_bsk_gat_ragged_1_32", "dagnet", dict(REAL, n_layers=2), [1, 32, 7], 4, 6, 49, 2, data_kind="sdd", g_cells=(9, 10))
     build_case("avrnn_bsk_gat_n33", "avrnn", dict(REAL, n_layers=1), [33, 2], 4, 5, 50, 1, data_kind="sdd")

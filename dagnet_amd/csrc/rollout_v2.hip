@@ -719,19 +719,25 @@ static hipError_t launch_one(const V2Weights *d_w, const V2Run &r, hipStream_t s
     return hipGetLastError();
 }
 
+// (model, GRU layers, z_dim) combinations with an instantiation: the shapes of the shipped checkpoints
+// (basketball: DAG-Net L2/Z32, A-VRNN L1/Z32, VRNN L2/Z32; SDD: A-VRNN L1/Z16, VRNN L2/Z16) plus A-VRNN L2/Z32
+#define V2_INSTANCES \
+    V2_CASE(2, 2, 32) V2_CASE(1, 1, 32) V2_CASE(0, 2, 32) V2_CASE(1, 1, 16) V2_CASE(0, 2, 16) V2_CASE(1, 2, 32)
+
 // returns hipErrorInvalidValue when the (model, layers, z) combination has no instantiation
 // d_w: DEVICE pointer to the model's V2Weights table
 extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, const V2Weights *d_w, const V2Run *r, hipStream_t st) {
 #define V2_CASE(M, L, Z) \
     if (model == M && n_layers == L && z_dim == Z) return launch_one<M, L, Z>(d_w, *r, st);
-    V2_CASE(2, 2, 32)
-    V2_CASE(1, 1, 32)
-    V2_CASE(0, 2, 32)
+    V2_INSTANCES
 #undef V2_CASE
     return hipErrorInvalidValue;
 }
 
 extern "C" int dn_v2_has(int model, int n_layers, int z_dim) {
-    return (model == 2 && n_layers == 2 && z_dim == 32) || (model == 1 && n_layers == 1 && z_dim == 32) ||
-           (model == 0 && n_layers == 2 && z_dim == 32);
+#define V2_CASE(M, L, Z) \
+    if (model == M && n_layers == L && z_dim == Z) return 1;
+    V2_INSTANCES
+#undef V2_CASE
+    return 0;
 }

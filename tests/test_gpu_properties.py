@@ -254,3 +254,20 @@ def test_errors_are_loud():
     with pytest.raises(_capi.DagnetHipError, match="n_max_agents"):
         m5.sample_k(1, 3, h, x0, g0, sse)
     assert m.sample_k(2, 0, h, x0, g0, sse).shape == (2, 0, 4, 2)
+
+
+@pytest.mark.parametrize("name,want", [
+    ("dagnet_bsk_gat_n10", "register-resident"), ("avrnn_bsk_gat", "register-resident"), ("vrnn_bsk", "register-resident"),
+    ("avrnn_sdd_gat", "register-resident"), ("vrnn_sdd", "register-resident"), ("avrnn_bsk_gat_L2_n10", "register-resident"),
+    ("dagnet_bsk_gat_ragged_1_32", "LDS-tiled"),      # n_max_agents = 32 > 16: disposition wider than one k-tile
+    ("avrnn_bsk_gat_n33", "LDS-tiled"),               # a 33-agent scene does not fit a 32-row wave tile
+    ("dagnet_bsk_gcn_n10", "LDS-tiled"), ("dagnet_tiny_gat_adj1", "LDS-tiled"), ("dagnet_sdd_gat_g960", "global scratch"),
+])
+def test_kernel_dispatch(name, want):
+    """Which kernel a golden case runs on (the parity tests cover both kernels only if the dispatch is as intended)."""
+    from tests import cases
+    meta, _ = cases.load_golden(name)
+    _, model, _ = cases.build_model(meta)
+    model = model.to(DEV)
+    sp = syn.scene_ptr(meta["sizes"]) if meta["kind"] != "vrnn" else np.arange(sum(meta["sizes"]) + 1, dtype=np.int32)
+    assert want in model.hip_plan(DEV, sp, meta["K"]).info()["sample_kernel"]

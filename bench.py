@@ -28,6 +28,22 @@ from dagnet_amd._runtime import scene_ptr_from_sse   # noqa: E402
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
+
+def pmc_traffic(workload, kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_pmc.json,
+    written by tools/profile_round.sh + tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, gfx950 correction applied).
+    None when no counter pass of this workload/kernel has been committed."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            ks = json.load(open(path)).get(workload, {}).get("kernels", {})
+        except (OSError, ValueError):
+            continue
+        for name, v in ks.items():
+            if kernel.split(" ")[0] + "<" in name and "traffic_bytes_per_launch" in v:
+                return float(v["traffic_bytes_per_launch"])
+    return None
+
 WORKLOADS = {
     # BASELINE.json configs[2]: DAG-Net full, basketball-shaped, 4096 scenes x 20 samples, 1 GPU
     "dagnet_bsk_4096x20": dict(kind="dagnet", scenes=4096, agents=10, K=20, obs=10, pred=40, args=dict(n_layers=2)),
@@ -226,7 +242,7 @@ def main():
                        "tile_rows": info["tile_rows"], "tiles": info["n_tiles"], "lds_bytes": info["lds_bytes"],
                        "parallelism": f"scenes sharded x{world}, 1 all-reduce of 3 doubles per step"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": pmc_traffic(opt.workload, info["sample_kernel"]),
                          "kernel": info["sample_kernel"], "kernel_ms": kernel_ms,
                          "flop_per_trajectory": fl},
             "forward_obs_ms": fwd_ms,

@@ -16,6 +16,7 @@
 #include "../../include/dagnet_hip.h"
 #include "params.h"
 #include "params_v2.h"
+#include "params_wide.h"
 
 extern "C" hipError_t dn_launch_rollout(int mode, const void *d_static, const DnRun *run, size_t lds_bytes, hipStream_t stream);
 extern "C" hipError_t dn_launch_adjacency(int type, double sigma, int top_k, const int32_t *scene_ptr, const int32_t *row_scene,
@@ -32,6 +33,27 @@ extern "C" hipError_t dn_launch_scene_min_sum(const int32_t *scene_ptr, int S, i
                                               float *scene_best, double *sums, hipStream_t st);
 extern "C" hipError_t dn_launch_rel_to_abs(int T, int N, const float *rel, const float *start, float *out, hipStream_t st);
 extern "C" hipError_t dn_launch_categorical(int N, int G, const float *w, const float *q, uint64_t seed, int32_t *out, hipStream_t st);
+
+struct WideStep {                     // wide_head.hip
+    const float *wp;
+    WideWeights w;
+    WideBuffers b;
+    const int32_t *scene_ptr, *row_scene;
+    const int64_t *off_compact;
+    int64_t compact;
+    int N, K, S, T, t;
+    int D, R, H, G, L, P, F;
+    int adj_type, top_k;
+    double sigma;
+    float alpha;
+    const float *q;
+    const int32_t *force_goals;
+    uint64_t seed;
+    int32_t *out_goals;
+};
+extern "C" hipError_t dn_wide_init_state(int N, int K, int L, int R, int G, const float *h0, const float *x0, const int32_t *g0,
+                                         float *h, float *pos, int32_t *goal, hipStream_t st);
+extern "C" hipError_t dn_wide_goal_head(const WideStep *sp, hipStream_t st);
 
 static thread_local char g_err[512] = "";
 
@@ -61,6 +83,9 @@ struct dagnet_model {
     bool v2 = false;            // the register-resident kernel (rollout_v2.hip) covers this model
     V2Weights w2;
     V2Weights *d_w2 = nullptr;  // device copy of w2
+    // wide goal head (wide_head.hip) + register-resident kernel model 3 for the rest of the step
+    bool wide = false;
+    WideWeights ww;
 };
 
 struct dagnet_plan {
@@ -80,6 +105,10 @@ struct dagnet_plan {
     float *d_gscratch = nullptr;
     int64_t gslab = 0;
     int gblocks = 0;
+    // wide goal head: layer-by-layer workspace over all K*N rows (one hipMalloc, carved into WideBuffers)
+    bool wide = false;
+    float *d_wide = nullptr;
+    WideBuffers wb;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -157,6 +186,14 @@ struct Packer {
                         }
         return off;
     }
+    // plain row-major [N][ld] (ld >= K, zero padded): operands of the batched GEMMs (gemm_f32.hip)
+    int rowmajor(const WFn &W, int N, int K, int ld) {
+        const int off = align();
+        buf.resize(off + (size_t)N * ld, 0.f);
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < K; ++k) buf[off + (size_t)n * ld + k] = W(n, k);
+        return off;
+    }
     int vec(const std::function<float(int)> &f, int n, int npad) {
         const int off = align();
         buf.resize(off + npad, 0.f);
@@ -175,6 +212,7 @@ struct Packer {
 
 struct SegSpec {
     int col0, K;
+    int kpad = 0;      // chain packing only: pad the segment with zero columns up to this width
 };
 
 // torch nn.Linear "name": weight [N][Ktot], bias [N]
@@ -371,7 +409,8 @@ V2Lin v2_linear(Packer &pk, const std::string &name, int N, int Ktot, std::vecto
     const float *w = W->p, *b = B->p;
     for (size_t s = 0; s < segs.size(); ++s) {
         const int c0 = segs[s].col0;
-        L.w[s] = pk.chain([=](int n, int k) { return w[(size_t)n * Ktot + c0 + k]; }, N, segs[s].K);
+        const int Ks = segs[s].K;
+        L.w[s] = pk.chain([=](int n, int k) { return k < Ks ? w[(size_t)n * Ktot + c0 + k] : 0.f; }, N, std::max(Ks, segs[s].kpad));
     }
     L.bias = pk.vec([=](int n) { return b[n]; }, N, pad32(N));
     if (gcol0 >= 0) L.gather = pk.gather([=](int n, int g) { return w[(size_t)n * Ktot + gcol0 + g]; }, N, G);
@@ -480,7 +519,86 @@ bool v2_eligible(const dagnet_config &c) {
     return true;
 }
 
-void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W) {
+static inline int pad4(int x) { return (x + 3) & ~3; }
+
+// DAG-Net with a goal head too wide for one wave's registers (g_dim > 96): wide_head.hip + rollout_v2 model 3
+bool wide_eligible(const dagnet_config &c) {
+    if (c.model != DAGNET_MODEL_DAGNET) return false;
+    if (c.x_dim != 2 || c.h_dim != 64 || c.rnn_dim != 64) return false;
+    if (!dn_v2_has(3, c.n_layers, c.z_dim)) return false;
+    if (c.graph_model != DAGNET_GRAPH_GAT || c.n_heads != 4 || c.graph_hid != 8) return false;
+    if (c.adjacency_type != 0 && c.adjacency_type != 1) return false;
+    if (c.g_dim <= 96 || (c.g_dim & 3) || c.n_max_agents > 32) return false;
+    return true;
+}
+
+void wide_pack(Packer &pk, const dagnet_config &c, WideWeights &W) {
+    memset(&W, 0, sizeof(W));
+    const int H = c.h_dim, R = c.rnn_dim, G = c.g_dim, Dd = 2 * c.n_max_agents, F = c.graph_hid, P = c.n_heads, PF = P * F;
+    const Tensor *W0 = pk.get("dec_goal.0.weight", {H, Dd + R + G}), *B0 = pk.get("dec_goal.0.bias", {H});
+    const Tensor *W2 = pk.get("dec_goal.2.weight", {G, H}), *B2 = pk.get("dec_goal.2.bias", {G});
+    const Tensor *Wl = pk.get("lg_goals.0.weight", {G, 2 * G}), *Bl = pk.get("lg_goals.0.bias", {G});
+    const Tensor *Wo = pk.get("graph_goals.out_att.W", {PF, G}), *ao = pk.get("graph_goals.out_att.a", {2 * G, 1});
+    if (!W0 || !B0 || !W2 || !B2 || !Wl || !Bl || !Wo || !ao) return;
+    std::vector<const float *> Wh(P), ah(P);
+    for (int p = 0; p < P; ++p) {
+        const Tensor *Wp_ = pk.get("graph_goals.attention_" + std::to_string(p) + ".W", {G, F});
+        const Tensor *ap_ = pk.get("graph_goals.attention_" + std::to_string(p) + ".a", {2 * F, 1});
+        if (!Wp_ || !ap_) return;
+        Wh[p] = Wp_->p;
+        ah[p] = ap_->p;
+    }
+    const int Ktot = Dd + R + G;
+    const float *w0 = W0->p, *b0 = B0->p, *w2 = W2->p, *b2 = B2->p, *wl = Wl->p, *bl = Bl->p, *wo = Wo->p, *aop = ao->p;
+    W.g0_ld = pad4(Dd + R);
+    W.g0_w = pk.rowmajor([=](int n, int k) { return w0[(size_t)n * Ktot + k]; }, H, Dd + R, W.g0_ld);
+    W.g0_b = pk.vec([=](int n) { return b0[n]; }, H, H);
+    W.g0_gld = H;
+    W.g0_gather = pk.rowmajor([=](int g, int n) { return w0[(size_t)n * Ktot + Dd + R + g]; }, G, H, H);
+    W.g2_ld = pad4(H);
+    W.g2_w = pk.rowmajor([=](int n, int k) { return w2[(size_t)n * H + k]; }, G, H, W.g2_ld);
+    W.g2_b = pk.vec([=](int n) { return b2[n]; }, G, G);
+    // heads: row p*F+f = W_p[:, f]; folded logits: row PF+p = W_p a_p[:F], row PF+P+p = W_p a_p[F:]  (x.(W a) == (x W).a)
+    W.hf_ld = pad4(G);
+    W.hf_w = pk.rowmajor(
+        [=](int n, int k) {
+            if (n < PF) return Wh[n / F][(size_t)k * F + (n % F)];
+            const int p = (n - PF) % P, dst = (n - PF) / P;
+            double acc = 0.0;
+            for (int f = 0; f < F; ++f) acc += (double)Wh[p][(size_t)k * F + f] * (double)ah[p][dst * F + f];
+            return (float)acc;
+        },
+        PF + 2 * P, G, W.hf_ld);
+    W.out_ld = pad4(PF);
+    W.out_w = pk.rowmajor([=](int n, int k) { return wo[(size_t)k * G + n]; }, G, PF, W.out_ld);
+    W.fold_out = pk.vec(
+        [=](int i) {
+            const int dst = i / PF, k = i % PF;
+            double acc = 0.0;
+            for (int n = 0; n < G; ++n) acc += (double)wo[(size_t)k * G + n] * (double)aop[dst * G + n];
+            return (float)acc;
+        },
+        2 * PF, 2 * PF);
+    const Tensor *g = pk.get("graph_goals.bn1.weight", {G}), *b = pk.get("graph_goals.bn1.bias", {G});
+    const Tensor *mu = pk.get("graph_goals.bn1.running_mean", {G}), *var = pk.get("graph_goals.bn1.running_var", {G});
+    if (!g || !b || !mu || !var) return;
+    const float *gp = g->p, *bp = b->p, *mp = mu->p, *vp = var->p;
+    W.bn = pk.vec(
+        [=](int i) {
+            const int cidx = i % G;
+            const float sc = gp[cidx] / sqrtf(vp[cidx] + 1e-5f);
+            return i < G ? sc : bp[cidx] - mp[cidx] * sc;
+        },
+        2 * G, 2 * G);
+    W.lg_ld = 2 * pad4(G);
+    const int Gp = pad4(G);
+    W.lg_w = pk.rowmajor([=](int n, int k) { return k < Gp ? (k < G ? wl[(size_t)n * 2 * G + k] : 0.f)
+                                                            : (k - Gp < G ? wl[(size_t)n * 2 * G + G + (k - Gp)] : 0.f); },
+                         G, 2 * Gp, W.lg_ld);
+    W.lg_b = pk.vec([=](int n) { return bl[n]; }, G, G);
+}
+
+void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false) {
     memset(&W, 0, sizeof(W));
     const int H = 64, R = 64, Z = c.z_dim, G = c.g_dim, Dd = 2 * c.n_max_agents;
     const bool dag = c.model == DAGNET_MODEL_DAGNET, graph = c.model != DAGNET_MODEL_VRNN;
@@ -492,7 +610,8 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W) {
     W.phi_z2 = v2_linear(pk, "phi_z.2", H, H, {{0, H}});
     if (dag) {
         W.prior0 = v2_linear(pk, "prior.0", H, G + R, {{G, R}}, 0, G);
-        W.dec0 = v2_linear(pk, "dec.0", H, Dd + G + H + R, {{0, Dd}, {Dd + G, H}, {Dd + G + H, R}}, Dd, G);
+        // model 3 multiplies two disposition tiles whatever n_max_agents is
+        W.dec0 = v2_linear(pk, "dec.0", H, Dd + G + H + R, {{0, Dd, ext ? 64 : 0}, {Dd + G, H}, {Dd + G + H, R}}, Dd, G);
     } else {
         W.prior0 = v2_linear(pk, "prior.0", H, R, {{0, R}});
         W.dec0 = v2_linear(pk, "dec.0", H, H + R, {{0, H}, {H, R}});
@@ -505,7 +624,7 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W) {
         W.g_hid = v2_gat(pk, dag ? "graph_hiddens" : "graph", R, R, c.graph_hid, c.n_heads);
         W.blend = v2_linear(pk, dag ? "lg_hiddens" : "lg", R, 2 * R, {{0, R}, {R, R}});
     }
-    if (dag) {
+    if (dag && !ext) {
         W.dec_goal0 = v2_linear(pk, "dec_goal.0", H, Dd + R + G, {{0, Dd}, {Dd, R}}, Dd + R, G);
         W.dec_goal2 = v2_linear(pk, "dec_goal.2", G, H, {{0, H}});
         W.g_goal = v2_gat(pk, "graph_goals", G, G, c.graph_hid, c.n_heads);
@@ -609,6 +728,11 @@ extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor
     }
     m->v2 = v2_eligible(c);
     if (m->v2 && pk.missing.empty()) v2_pack(pk, c, m->w2);
+    m->wide = !m->v2 && wide_eligible(c) && !getenv("DAGNET_NO_WIDE");
+    if (m->wide && pk.missing.empty()) {
+        v2_pack(pk, c, m->w2, true);
+        wide_pack(pk, c, m->ww);
+    }
     if (!pk.missing.empty()) {
         const int rc = fail(DAGNET_ERR_MISSING, "state dict entry missing or mis-shaped: %s", pk.missing.c_str());
         delete m;
@@ -619,7 +743,7 @@ extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor
     hipError_t e = hipGetDevice(&m->device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_wp), m->wp_floats * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(m->d_wp, pk.buf.data(), m->wp_floats * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess && m->v2) {
+    if (e == hipSuccess && (m->v2 || m->wide)) {
         e = hipMalloc(reinterpret_cast<void **>(&m->d_w2), sizeof(V2Weights));
         if (e == hipSuccess) e = hipMemcpy(m->d_w2, &m->w2, sizeof(V2Weights), hipMemcpyHostToDevice);
     }
@@ -765,7 +889,7 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
         u += cnt;
     }
     std::vector<int32_t> u2, nu2;
-    if (m && m->v2 && nmax <= 32) {
+    if (m && (m->v2 || m->wide) && nmax <= 32) {
         int64_t v = 0;
         while (v < units) {
             int rows = 0, cnt = 0;
@@ -820,6 +944,34 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
         P.w = m->w;
         up(&p->d_static, &P, offsetof(DnParams, r));
     }
+    if (m && m->wide && nmax <= 32 && e == hipSuccess) {
+        // layer-by-layer workspace of the wide goal head, carved from one allocation (64-float aligned pieces)
+        const DnDims &D = m->dims;
+        const int64_t rows = (int64_t)N * K, Gp = (D.G + 3) & ~3, PF = D.P * D.F;
+        WideBuffers &b = p->wb;
+        memset(&b, 0, sizeof(b));
+        b.a0_ld = m->ww.g0_ld;
+        b.hs_ld = (PF + 2 * D.P + 3) & ~3;
+        b.Gp = Gp;
+        int64_t off = 0;
+        auto take = [&](int64_t floats) {
+            const int64_t o = off;
+            off += (floats + 63) & ~(int64_t)63;
+            return o;
+        };
+        const int64_t oA0 = take(rows * b.a0_ld), oT1 = take(rows * D.H), oA1 = take(rows * 2 * Gp), oB = take(rows * Gp),
+                      oHS = take(rows * b.hs_ld), oX2 = take(rows * PF), oS2 = take(rows * 2), oadj = take((int64_t)K * acc),
+                      oh = take((int64_t)D.L * rows * D.R), opos = take(rows * 2), ogoal = take(rows);
+        e = hipMalloc(reinterpret_cast<void **>(&p->d_wide), sizeof(float) * off);
+        if (e == hipSuccess) e = hipMemset(p->d_wide, 0, sizeof(float) * off);
+        if (e == hipSuccess) {
+            float *w = p->d_wide;
+            b.A0 = w + oA0; b.T1 = w + oT1; b.A1 = w + oA1; b.B = w + oB; b.HS = w + oHS; b.X2 = w + oX2; b.S2 = w + oS2;
+            b.adj = w + oadj; b.h = w + oh; b.pos = w + opos;
+            b.goal = reinterpret_cast<int32_t *>(w + ogoal);
+            p->wide = true;
+        }
+    }
     if (e != hipSuccess) {
         dagnet_plan_destroy(p);
         return fail(DAGNET_ERR_HIP, "plan upload failed: %s", hipGetErrorString(e));
@@ -830,7 +982,7 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
 
 extern "C" void dagnet_plan_destroy(dagnet_plan *p) {
     if (!p) return;
-    void *ptrs[] = {p->d_scene_ptr, p->d_tile_u0, p->d_tile_nu, p->d_row_scene, p->d_off_dense, p->d_off_compact, p->d_loss_part, p->d_static, p->d_tile2_u0, p->d_tile2_nu, p->d_gscratch};
+    void *ptrs[] = {p->d_scene_ptr, p->d_tile_u0, p->d_tile_nu, p->d_row_scene, p->d_off_dense, p->d_off_compact, p->d_loss_part, p->d_static, p->d_tile2_u0, p->d_tile2_nu, p->d_gscratch, p->d_wide};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
     delete p;
@@ -910,6 +1062,36 @@ extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_
         else r.prof = g_prof;
 #endif
         HIP_TRY(dn_launch_rollout_v2(m->dims.model, m->dims.L, m->dims.Z, m->d_w2, &r, static_cast<hipStream_t>(stream)));
+        return DAGNET_OK;
+    }
+    if (m->wide && p->wide && !getenv("DAGNET_FORCE_GENERIC")) {
+        // wide goal head: per step, the goal head layer by layer over all K*N rows, then one step of the
+        // register-resident kernel (model 3) with the drawn goals; state lives in the plan's workspace
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        const DnDims &D = m->dims;
+        HIP_TRY(dn_wide_init_state(p->N, p->K, D.L, D.R, D.G, d_h0, d_x0, d_g0, p->wb.h, p->wb.pos, p->wb.goal, st));
+        WideStep ws;
+        memset(&ws, 0, sizeof(ws));
+        ws.wp = m->d_wp; ws.w = m->ww; ws.b = p->wb;
+        ws.scene_ptr = p->d_scene_ptr; ws.row_scene = p->d_row_scene; ws.off_compact = p->d_off_compact; ws.compact = p->compact_size;
+        ws.N = p->N; ws.K = p->K; ws.S = p->S; ws.T = T;
+        ws.D = D.D; ws.R = D.R; ws.H = D.H; ws.G = D.G; ws.L = D.L; ws.P = D.P; ws.F = D.F;
+        ws.adj_type = D.adj_type; ws.top_k = D.knn_k; ws.sigma = D.sigma; ws.alpha = D.alpha;
+        ws.q = d_q; ws.force_goals = d_force_goals; ws.seed = seed; ws.out_goals = d_out_goals;
+        V2Run r;
+        memset(&r, 0, sizeof(r));
+        r.wp = m->d_wp;
+        r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
+        r.S = p->S; r.N = p->N; r.K = p->K; r.T = T; r.n_tiles = p->n_tiles2;
+        r.G = D.G; r.D = D.D; r.adj_type = D.adj_type; r.alpha = D.alpha; r.sigma = D.sigma;
+        r.h0 = p->wb.h; r.x0 = p->wb.pos; r.g0 = p->wb.goal; r.eps = d_eps; r.seed = seed; r.out = d_out;
+        r.h_out = p->wb.h; r.x_out = p->wb.pos;
+        for (int t = 0; t < T; ++t) {
+            ws.t = t;
+            HIP_TRY(dn_wide_goal_head(&ws, st));
+            r.t_begin = t; r.t_end = t + 1;
+            HIP_TRY(dn_launch_rollout_v2(3, D.L, D.Z, m->d_w2, &r, st));
+        }
         return DAGNET_OK;
     }
     DnParams P;
@@ -996,6 +1178,7 @@ extern "C" int dagnet_adjacency(const dagnet_plan *p, int32_t adjacency_type, do
 }
 
 extern "C" int dagnet_plan_kernel(const dagnet_plan *p) {
+    if (p && p->wide && p->owner && p->owner->wide && !getenv("DAGNET_FORCE_GENERIC")) return 3;
     if (!p || !p->owner) return -1;
     if (p->owner->v2 && p->n_tiles2 > 0 && !getenv("DAGNET_FORCE_GENERIC")) return 2;
     return p->big ? 1 : 0;

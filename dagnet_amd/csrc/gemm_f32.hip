@@ -1,0 +1,292 @@
+// fp32 MFMA GEMMs for the layer-by-layer paths (wide goal head of SDD-shaped DAG-Net, training step).
+//
+//   NT:  C[M,N] = act(A[M,K] . W[N,K]^T + bias[N])            nn.Linear forward        (models/dagnet/model.py:60-113)
+//   TN:  C[N,K] = sum_m A[m,N] . B[m,K]   (split over m)      weight gradients
+//
+// 256 threads = 4 waves per workgroup; every wave owns TM x TN accumulator tiles of v_mfma_f32_32x32x2_f32
+// (exact fp32 products, fp32 accumulation).  Operands are staged through LDS in k-chunks of 32, double buffered,
+// register-staged global loads (float4 per lane, 128 B per 8 lanes).  The k index inside a chunk is permuted
+// (MFMA number 4j+i of a chunk consumes k = 8j + 4h + i in lane half h) so that each lane fetches its operands as
+// one ds_read_b128 per 4 MFMAs; any permutation is legal because both operands use the same one.
+// Row stride of the LDS tiles is 36 floats: 16 consecutive rows x 16 B then cover all 64 banks exactly once.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;        // k-chunk
+constexpr int LDT = BK + 4;   // LDS row stride (floats)
+
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_RELU = 3 };
+
+struct NtArgs {
+    const float *A; int64_t lda;      // [M, K]
+    const float *W; int64_t ldw;      // [N, K]
+    const float *bias;                // [N] or null
+    float *C; int64_t ldc;            // [M, N]
+    int M, N, K;
+    float slope;                      // LeakyReLU slope
+    // optional one-hot input folded into the epilogue: C[m][n] += gather[gidx[m] * ldg + n]
+    const float *gather; const int32_t *gidx; int64_t ldg;
+};
+
+__device__ __forceinline__ float act_apply(int act, float v, float slope) {
+    if (act == ACT_LRELU) return fmaxf(v, v * slope);
+    if (act == ACT_TANH) return tanhf(v);
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    return v;
+}
+
+// Wave grid WM x WN (WM*WN == 4), per-wave TM x TN tiles of 32x32.  Tile of the workgroup: (WM*TM*32) x (WN*TN*32).
+template <int WM, int WN, int TM, int TN, int ACT>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;      // float4 loads per thread and chunk
+    static_assert(LA >= 1 && LB >= 1, "tile too small for 256 threads");
+    extern __shared__ float smem[];
+    float *sA = smem;                       // [2][BM][LDT]
+    float *sB = smem + 2 * BM * LDT;        // [2][BN][LDT]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    // column blocks vary fastest: consecutive workgroups share the A rows (L2 reuse inside an XCD round robin is
+    // irrelevant here because W is small enough to stay resident in every L2)
+    const int nbn = (p.N + BN - 1) / BN;
+    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+    const int m0 = bm * BM, n0 = bn * BN;
+
+    const int lrow = tid >> 3, lc4 = (tid & 7) * 4;          // this thread's (row, k) inside a 32-row slab of a chunk
+    f32x4 ga[LA], gb[LB];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) {
+            const int r = m0 + lrow + 32 * i, k = k0 + lc4;
+            ga[i] = (r < p.M && k < p.K) ? *reinterpret_cast<const f32x4 *>(p.A + (int64_t)r * p.lda + k) : f32x4{0, 0, 0, 0};
+        }
+#pragma unroll
+        for (int i = 0; i < LB; ++i) {
+            const int r = n0 + lrow + 32 * i, k = k0 + lc4;
+            gb[i] = (r < p.N && k < p.K) ? *reinterpret_cast<const f32x4 *>(p.W + (int64_t)r * p.ldw + k) : f32x4{0, 0, 0, 0};
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4 *>(sA + (buf * BM + lrow + 32 * i) * LDT + lc4) = ga[i];
+#pragma unroll
+        for (int i = 0; i < LB; ++i) *reinterpret_cast<f32x4 *>(sB + (buf * BN + lrow + 32 * i) * LDT + lc4) = gb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) gload((kc + 1) * BK);
+        const float *a_base = sA + (buf * BM + (wm * TM) * 32 + lr) * LDT + 4 * lh;
+        const float *b_base = sB + (buf * BN + (wn * TN) * 32 + lr) * LDT + 4 * lh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const f32x4 *>(a_base + a * 32 * LDT + 8 * j);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const f32x4 *>(b_base + b * 32 * LDT + 8 * j);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][i], fb[b][i], acc[a][b], 0, 0, 0);
+        }
+        if (kc + 1 < nk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lane = output column, register r <-> row (r&3) + 8(r>>2) + 4h of the 32x32 tile
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int col = n0 + (wn * TN + b) * 32 + lr;
+        const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int rbase = m0 + (wm * TM + a) * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                if (row < p.M && col < p.N) {
+                    float v = acc[a][b][r] + bv;
+                    if (p.gather) v += p.gather[(int64_t)p.gidx[row] * p.ldg + col];
+                    p.C[(int64_t)row * p.ldc + col] = act_apply(ACT, v, p.slope);
+                }
+            }
+        }
+    }
+}
+
+struct TnArgs {
+    const float *A; int64_t lda;      // [M, N]  (e.g. dY)
+    const float *B; int64_t ldb;      // [M, K]  (e.g. X)
+    float *C; int64_t ldc;            // [splits][N, K] partial sums, split stride = N*ldc
+    int M, N, K;
+    int rows_per_split;               // multiple of 32
+};
+
+// C_split[n][k] = sum over this split's rows m of A[m][n] * B[m][k].  Workgroup tile 64 x 64 (2x2 waves, 1 tile each),
+// reduction chunks of 32 rows; LDS tiles are [m][n] / [m][k] as loaded, operands fetched as ds_read_b32.
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
+    __shared__ float sA[2][32][64 + 1], sB[2][32][64 + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
+    const int nbk = (p.K + 63) / 64;
+    const int n0 = (blockIdx.x / nbk) * 64, k0 = (blockIdx.x % nbk) * 64;
+    const int mbeg = blockIdx.y * p.rows_per_split, mend = min(p.M, mbeg + p.rows_per_split);
+    const int lrow = tid >> 4, lc4 = (tid & 15) * 4;          // 16 rows x 16 float4 per pass, 2 passes per 32-row chunk
+    const bool vecA = (p.lda & 3) == 0, vecB = (p.ldb & 3) == 0;
+    f32x4 ga[2], gb[2];
+    auto ld4 = [&](const float *base, int64_t ld, int row, int col, int ncol, bool vec) {
+        f32x4 v = {0, 0, 0, 0};
+        if (row < mend) {
+            const float *q = base + (int64_t)row * ld + col;
+            if (vec && col + 3 < ncol) v = *reinterpret_cast<const f32x4 *>(q);
+            else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (col + i < ncol) v[i] = q[i];
+            }
+        }
+        return v;
+    };
+    auto gload = [&](int m) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ga[i] = ld4(p.A, p.lda, m + lrow + 16 * i, n0 + lc4, p.N, vecA);
+            gb[i] = ld4(p.B, p.ldb, m + lrow + 16 * i, k0 + lc4, p.K, vecB);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                sA[buf][lrow + 16 * i][lc4 + c] = ga[i][c];
+                sB[buf][lrow + 16 * i][lc4 + c] = gb[i][c];
+            }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int nchunk = (mend - mbeg + 31) / 32;
+    if (nchunk > 0) {
+        gload(mbeg);
+        sstore(0);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunk) gload(mbeg + (c + 1) * 32);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[buf][2 * kk + lh][wm * 32 + lr], sB[buf][2 * kk + lh][wn * 32 + lr], acc, 0, 0, 0);
+        if (c + 1 < nchunk) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    float *C = p.C + (int64_t)blockIdx.y * p.N * p.ldc;
+    const int col = k0 + wn * 32 + lr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = n0 + wm * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
+        if (row < p.N && col < p.K) C[(int64_t)row * p.ldc + col] = acc[r];
+    }
+}
+
+// out[i] (+)= sum_s part[s][i]   (deterministic second pass of the split reduction)
+__global__ void reduce_splits_kernel(const float *part, int64_t stride, int splits, int64_t n, float *out, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = accumulate ? out[i] : 0.f;
+    for (int k = 0; k < splits; ++k) s += part[k * stride + i];
+    out[i] = s;
+}
+
+template <int WM, int WN, int TM, int TN>
+static hipError_t launch_nt_cfg(const NtArgs &a, int act, hipStream_t st) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
+    const int64_t blocks = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    if (blocks <= 0) return hipSuccess;
+    if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
+    switch (act) {
+    case ACT_NONE: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, ACT_NONE>), dim3((unsigned)blocks), dim3(256), lds, st, a); break;
+    case ACT_LRELU: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, ACT_LRELU>), dim3((unsigned)blocks), dim3(256), lds, st, a); break;
+    case ACT_TANH: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, ACT_TANH>), dim3((unsigned)blocks), dim3(256), lds, st, a); break;
+    case ACT_RELU: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, ACT_RELU>), dim3((unsigned)blocks), dim3(256), lds, st, a); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace gemm
+
+// C = act(A W^T + bias).  Requires lda, ldw multiples of 4 floats and 16-byte aligned A, W (the float4 staging loads);
+// K is zero-filled per float4, so K must be a multiple of 4 as well.  ldc is free.
+extern "C" hipError_t dn_gemm_nt_gather(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *C,
+                                        int64_t ldc, int M, int N, int K, int act, float slope, const float *gather,
+                                        const int32_t *gidx, int64_t ldg, hipStream_t st) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if ((lda & 3) || (ldw & 3) || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15))
+        return hipErrorInvalidValue;
+    gemm::NtArgs a{A, lda, W, ldw, bias, C, ldc, M, N, K, slope, gather, gidx, ldg};
+    if (N > 64) return gemm::launch_nt_cfg<2, 2, 2, 2>(a, act, st);     // 128 x 128
+    if (N > 32) return gemm::launch_nt_cfg<4, 1, 2, 2>(a, act, st);     // 256 x 64
+    return gemm::launch_nt_cfg<4, 1, 2, 1>(a, act, st);                 // 256 x 32
+}
+
+extern "C" hipError_t dn_gemm_nt(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *C, int64_t ldc,
+                                 int M, int N, int K, int act, float slope, hipStream_t st) {
+    return dn_gemm_nt_gather(A, lda, W, ldw, bias, C, ldc, M, N, K, act, slope, nullptr, nullptr, 0, st);
+}
+
+// C[N,K] (+)= A[M,N]^T B[M,K], deterministic two-pass split over M.  `part` is a workspace of
+// dn_gemm_tn_workspace(M, N, K) floats.
+extern "C" int64_t dn_gemm_tn_splits(int M) {
+    int64_t s = (M + 4095) / 4096;
+    return s < 1 ? 1 : (s > 256 ? 256 : s);
+}
+extern "C" int64_t dn_gemm_tn_workspace(int M, int N, int K) { return dn_gemm_tn_splits(M) * (int64_t)N * K; }
+extern "C" hipError_t dn_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int M, int N, int K,
+                                 float *part, int accumulate, hipStream_t st) {
+    if (N <= 0 || K <= 0) return hipSuccess;
+    const int splits = (int)dn_gemm_tn_splits(M);
+    int rows = (M + splits - 1) / splits;
+    rows = (rows + 31) & ~31;
+    if (rows < 32) rows = 32;
+    gemm::TnArgs a{A, lda, B, ldb, part, K, M, N, K, rows};
+    const int blocks = ((N + 63) / 64) * ((K + 63) / 64);
+    hipLaunchKernelGGL(gemm::gemm_tn_kernel, dim3(blocks, splits), dim3(256), 0, st, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    // the second pass writes rows of C with stride ldc: handle ldc == K in one launch, else row by row
+    if (ldc == K) {
+        const int64_t n = (int64_t)N * K;
+        hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, n, splits, n, C, accumulate);
+    } else {
+        for (int r = 0; r < N; ++r)
+            hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((K + 255) / 256), dim3(256), 0, st, part + (int64_t)r * K, (int64_t)N * K,
+                               splits, (int64_t)K, C + (int64_t)r * ldc, accumulate);
+    }
+    return hipGetLastError();
+}

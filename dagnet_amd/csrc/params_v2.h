@@ -56,6 +56,9 @@ struct V2Run {
     uint64_t seed;
     float *out;
     int32_t *out_goals;
+    // model 3 (goal head outside the kernel): steps [t_begin, t_end) of T, state per (sample, row), written back
+    int32_t t_begin, t_end;
+    float *h_out, *x_out;
     long long *prof;                 // DN_PROFILE builds: per-phase cycle counters of tile 0
     float *dbg;                      // debug builds: tile dumps of the first step of tile 0 (else NULL)
 };

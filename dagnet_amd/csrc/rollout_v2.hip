@@ -359,7 +359,9 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
     return pre;
 }
 
-// MODEL: 0 VRNN, 1 A-VRNN, 2 DAG-Net.  NL: GRU layers.  ZT: 32 -> z_dim 32, 16 -> z_dim 16.
+// MODEL: 0 VRNN, 1 A-VRNN, 2 DAG-Net, 3 DAG-Net whose goal head runs outside this kernel (wide_head.hip: the goal of the
+// step is read from the per-sample goal state; state is per (sample, row) and written back after the last step).
+// NL: GRU layers.  ZT: 32 -> z_dim 32, 16 -> z_dim 16.
 template <int MODEL, int NL, int ZD>
 __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
     const V2Weights &W = *Wp;     // offsets are fetched with scalar loads where they are used (no SGPR residency)
@@ -370,8 +372,10 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
     WBuf wp;
     wp.init(R.wp);
-    constexpr bool DAG = MODEL == 2, GRAPH = MODEL != 0;
+    constexpr bool DAG = MODEL >= 2, GRAPH = MODEL != 0, HEAD = MODEL == 2, EXT = MODEL == 3;
     constexpr int GT = 3;                   // goal tiles (g_dim <= 96)
+    constexpr int DT = EXT ? 2 : 1;         // disposition tiles (2 * n_max_agents <= 32 * DT)
+    const int t_begin = EXT ? R.t_begin : 0, t_end = EXT ? R.t_end : R.T;
 
     // ---- which rows does this wave own?  (uniform scalar walk over the tile's scene-samples)
     int s0 = lc, n = 1, grow = -1, krow = 0;      // padding lanes: a one-agent scene of their own, never written
@@ -389,6 +393,9 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     const bool live = grow >= 0;
     const int64_t NK = R.N;
     const uint32_t rngrow = (uint32_t)(krow * R.N + (live ? grow : 0));
+    // state row: the K samples share h0/x0/g0 ([.., N, ..]) unless the state is per sample ([.., K*N, ..])
+    const int64_t HN = EXT ? (int64_t)R.N * R.K : (int64_t)R.N;
+    const int64_t srow = EXT ? (int64_t)krow * R.N + grow : (int64_t)grow;
 
     // ---- state
     T16 h[NL][2];
@@ -399,17 +406,16 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (live) v = *reinterpret_cast<const float4 *>(R.h0 + ((int64_t)l * R.N + grow) * 64 + nt * 32 + 8 * a + 4 * lh);
+                if (live) v = *reinterpret_cast<const float4 *>(R.h0 + ((int64_t)l * HN + srow) * 64 + nt * 32 + 8 * a + 4 * lh);
                 h[l][nt][4 * a + 0] = v.x; h[l][nt][4 * a + 1] = v.y; h[l][nt][4 * a + 2] = v.z; h[l][nt][4 * a + 3] = v.w;
             }
     float xa = 0.f, ya = 0.f;
     int gi = 0;
-    if (GRAPH && live) { xa = R.x0[grow * 2]; ya = R.x0[grow * 2 + 1]; }
-    if (DAG && live) gi = min(max(R.g0[grow], 0), R.G - 1);
+    if (GRAPH && live) { xa = R.x0[srow * 2]; ya = R.x0[srow * 2 + 1]; }
+    if (DAG && live) gi = min(max(R.g0[srow], 0), R.G - 1);
     unsigned amask = 0;
 
-
-    const int first_off = DAG ? W.dec_goal0.w[0] : W.prior0.w[0];
+    const int first_off = HEAD ? W.dec_goal0.w[0] : W.prior0.w[0];
     WBlk pre = wload(wp, first_off, lane);
 #ifdef DN_PROFILE
     long long pstamp = clock64();
@@ -434,7 +440,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #define DBG(stage, arr, NTILES)
 #endif
     const int lane0 = lane, s00 = s0, n0 = n;
-    for (int t = 0; t < R.T; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         // Lane predicates (v_cmp results) live in SGPR pairs; if the compiler hoists the ~150 loop-invariant ones
         // out of the time loop they spill.  Re-deriving the lane ids from an opaque copy once per step keeps
         // them local to the step.
@@ -461,8 +467,19 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             }
             amask = mk;
         };
-        T16 d[1];
-        if (DAG) {
+        T16 d[DT];
+        auto build_disposition = [&]() {    // flattened xy of the scene's agents, zero padded
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = dt * 32 + FR(r) + 4 * lh, j = f >> 1;
+                    const float pv = pos[min(s0 + j, 31) * 2 + (f & 1)];
+                    d[dt][r] = ((f < R.D) & (j < n)) ? pv : 0.f;
+                }
+        };
+        if constexpr (EXT) build_mask();    // PRE-update positions; the goal of this step is already in the goal state
+        if constexpr (HEAD) {
             if constexpr (NL == 2) {        // h[0] is not read until the GRU: park it in LDS, the goal head needs the registers
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
@@ -470,13 +487,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
                     for (int r = 0; r < 16; ++r) stash[((2 + nt) * 16 + r) * 64 + lane] = h[0][nt][r];
             }
             build_mask();                   // PRE-update positions (models/dagnet/model.py:215-220)
-            // disposition: flattened xy of the scene's agents, zero padded
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = FR(r) + 4 * lh, j = f >> 1;
-                const float pv = pos[min(s0 + j, 31) * 2 + (f & 1)];
-                d[0][r] = ((f < R.D) & (j < n)) ? pv : 0.f;
-            }
+            build_disposition();
             PH(0);
             // ---------------------------------------------------------------- goal head
             T16 tg[2];
@@ -545,7 +556,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             if (R.out_goals && live && lh == 0) R.out_goals[((int64_t)krow * R.T + t) * NK + grow] = gi;
         }
         PH(3);
-        if constexpr (DAG) {
+        if constexpr (HEAD) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -615,13 +626,8 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         zero(ta);
         if (DAG) {
             // rebuilt from the positions in LDS (unchanged since the start of the step) rather than kept live
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = FR(r) + 4 * lh, j = f >> 1;
-                const float pv = pos[min(s0 + j, 31) * 2 + (f & 1)];
-                d[0][r] = ((f < R.D) & (j < n)) ? pv : 0.f;
-            }
-            pre = mm<2, 1, false>(ta, wp, W.dec0.w[0], d, lane, pre, W.dec0.w[1]);
+            build_disposition();
+            pre = mm<2, DT, false>(ta, wp, W.dec0.w[0], d, lane, pre, W.dec0.w[1]);
             pre = mm<2, 2, false>(ta, wp, W.dec0.w[1], pz, lane, pre, W.dec0.w[2]);
             pre = mm<2, 2, false>(ta, wp, W.dec0.w[2], h[NL - 1], lane, pre, W.dec2.w[0]);
         } else {
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         }
         PH(7);
         // -------------------------------------------------------------------- GRU
-        if constexpr (DAG && NL == 2) {
+        if constexpr (HEAD && NL == 2) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -709,6 +715,19 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         }
         PH(9);
     }
+    if constexpr (EXT) {    // write the state back (each wave touches only its own rows: in place is safe)
+        if (live) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        *reinterpret_cast<float4 *>(R.h_out + ((int64_t)l * HN + srow) * 64 + nt * 32 + 8 * a + 4 * lh) =
+                            make_float4(h[l][nt][4 * a], h[l][nt][4 * a + 1], h[l][nt][4 * a + 2], h[l][nt][4 * a + 3]);
+            if (lh == 0) *reinterpret_cast<float2 *>(R.x_out + srow * 2) = make_float2(xa, ya);
+        }
+    }
 }
 
 }   // namespace v2
@@ -722,7 +741,7 @@ static hipError_t launch_one(const V2Weights *d_w, const V2Run &r, hipStream_t s
 // (model, GRU layers, z_dim) combinations with an instantiation: the shapes of the shipped checkpoints
 // (basketball: DAG-Net L2/Z32, A-VRNN L1/Z32, VRNN L2/Z32; SDD: A-VRNN L1/Z16, VRNN L2/Z16) plus A-VRNN L2/Z32
 #define V2_INSTANCES \
-    V2_CASE(2, 2, 32) V2_CASE(1, 1, 32) V2_CASE(0, 2, 32) V2_CASE(1, 1, 16) V2_CASE(0, 2, 16) V2_CASE(1, 2, 32)
+    V2_CASE(2, 2, 32) V2_CASE(1, 1, 32) V2_CASE(0, 2, 32) V2_CASE(1, 1, 16) V2_CASE(0, 2, 16) V2_CASE(1, 2, 32) V2_CASE(3, 2, 32)
 
 // returns hipErrorInvalidValue when the (model, layers, z) combination has no instantiation
 // d_w: DEVICE pointer to the model's V2Weights table

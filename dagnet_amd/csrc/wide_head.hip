@@ -1,0 +1,337 @@
+// Wide goal head of DAGNet.sample (models/dagnet/model.py:215-235) for g_dim in the hundreds, one layer at a time over
+// all K*N rows of the batch.  Dense layers are fp32 MFMA GEMMs (gemm_f32.hip); this file holds the row-wise and
+// per-scene kernels between them and the per-step driver.  Row r = k*N + g (sample k, batch row g).
+//
+//   A0 = [d_t | h_last]                                   wide_goal_in_kernel
+//   T1 = relu(A0 W0^T + b0 + W0[:, goal_prev])            GEMM (gather epilogue)
+//   A1[:, :G] = softmax(T1 W2^T + b2)                     GEMM + wide_softmax_kernel
+//   HS = A1[:, :G] [heads | folded logits]^T              GEMM (N = P*F + 2P)
+//   X2 = elu(per-head attention), S2 = X2 fold_out^T      wide_attn_heads_kernel
+//   B  = X2 Wout^T                                        GEMM
+//   A1[:, G:] = tanh(bn(attention over B))                wide_attn_out_kernel
+//   B  = A1 Wlg^T + blg                                   GEMM (K = 2G)
+//   goal = argmax_g exp(softmax(B)_g) / q_g               wide_draw_kernel
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "params_wide.h"
+#include "rng.h"
+
+extern "C" hipError_t dn_gemm_nt_gather(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *C,
+                                        int64_t ldc, int M, int N, int K, int act, float slope, const float *gather,
+                                        const int32_t *gidx, int64_t ldg, hipStream_t st);
+extern "C" hipError_t dn_launch_adjacency(int type, double sigma, int top_k, const int32_t *scene_ptr, const int32_t *row_scene,
+                                          const int64_t *blk_off, int N, int T, const float *pos, float *out, int64_t ld,
+                                          int64_t tstride, hipStream_t st);
+
+namespace wide {
+
+enum { ACT_NONE = 0, ACT_RELU = 3 };    // gemm_f32.hip
+
+// state of every (sample, row): the K samples start from the same h / position / goal
+__global__ void init_state_kernel(int N, int K, int L, int R, int G, const float *__restrict__ h0, const float *__restrict__ x0,
+                                  const int32_t *__restrict__ g0, float *__restrict__ h, float *__restrict__ pos,
+                                  int32_t *__restrict__ goal) {
+    const int64_t rows = (int64_t)N * K;
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)L * rows * R;
+    if (idx < total) {
+        const int f = (int)(idx % R);
+        const int64_t lr = idx / R;
+        const int64_t r = lr % rows;
+        const int l = (int)(lr / rows);
+        h[idx] = h0[((int64_t)l * N + r % N) * R + f];
+    }
+    if (idx < rows) {
+        const int g = (int)(idx % N);
+        pos[idx * 2] = x0[g * 2];
+        pos[idx * 2 + 1] = x0[g * 2 + 1];
+        goal[idx] = min(max(g0[g], 0), G - 1);
+    }
+}
+
+// A0[r] = [disposition of r's scene (flattened xy of its agents, zero padded to D) | h_last[r] | 0 pad]
+__global__ void goal_in_kernel(int N, int K, int D, int R, int64_t ld, const int32_t *__restrict__ scene_ptr,
+                               const int32_t *__restrict__ row_scene, const float *__restrict__ pos, const float *__restrict__ hl,
+                               float *__restrict__ A0) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)N * K * ld) return;
+    const int c = (int)(idx % ld);
+    const int64_t r = idx / ld;
+    float v = 0.f;
+    if (c < D) {
+        const int g = (int)(r % N);
+        const int64_t kb = r - g;
+        const int s = row_scene[g];
+        const int b = scene_ptr[s], n = scene_ptr[s + 1] - b;
+        const int j = c >> 1;
+        if (j < n) v = pos[(kb + b + j) * 2 + (c & 1)];
+    } else if (c < D + R) {
+        v = hl[r * R + (c - D)];
+    }
+    A0[idx] = v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// in-place softmax over the first G columns of every row; one wave per row
+__global__ void softmax_kernel(int64_t rows, int G, int64_t ld, float *__restrict__ x) {
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float *p = x + r * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < G; c += 64) mx = fmaxf(mx, p[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < G; c += 64) s += expf(p[c] - mx);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int c = lane; c < G; c += 64) p[c] = expf(p[c] - mx) * inv;
+}
+
+// attention heads of graph_goals (gat_layers.py:25-40 with concat=True), one thread per (row, head):
+//   e_ij = leakyrelu(s_src_i + s_dst_j), masked by adj > 0, softmax over the scene, h'_i = elu(sum_j a_ij Wh_j)
+// and the folded logits of the out head: S2[i] = [X2_i . (W_out a_src), X2_i . (W_out a_dst)]
+template <int P, int F>
+__global__ void attn_heads_kernel(int N, int K, const int32_t *__restrict__ scene_ptr, const int32_t *__restrict__ row_scene,
+                                  const int64_t *__restrict__ off_compact, int64_t compact, const float *__restrict__ adj,
+                                  const float *__restrict__ HS, int64_t hs_ld, const float *__restrict__ fold_out, float alpha,
+                                  float *__restrict__ X2, float *__restrict__ S2) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = idx < (int64_t)N * K * P;
+    const int p = (int)(idx % P);
+    const int64_t r = live ? idx / P : 0;
+    const int g = (int)(r % N), k = (int)(r / N);
+    const int s = row_scene[g];
+    const int b = scene_ptr[s], n = scene_ptr[s + 1] - b;
+    const int64_t r0 = (int64_t)k * N + b;
+    const float *arow = adj + (int64_t)k * compact + off_compact[s] + (int64_t)(g - b) * n;
+    const float ssrc = HS[r * hs_ld + P * F + p];
+    float mx = -INFINITY;
+    for (int j = 0; j < n; ++j)
+        if (arow[j] > 0.f) {
+            const float e = ssrc + HS[(r0 + j) * hs_ld + P * F + P + p];
+            mx = fmaxf(mx, fmaxf(e, e * alpha));
+        }
+    float acc[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc[f] = 0.f;
+    float sum = 0.f;
+    for (int j = 0; j < n; ++j)
+        if (arow[j] > 0.f) {
+            const float *hj = HS + (r0 + j) * hs_ld;
+            const float e = ssrc + hj[P * F + P + p];
+            const float w = expf(fmaxf(e, e * alpha) - mx);
+            sum += w;
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc[f] += w * hj[p * F + f];
+        }
+    const float inv = 1.0f / sum;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        float v = acc[f] * inv;
+        v = v > 0.f ? v : expm1f(v);
+        if (live) X2[r * (P * F) + p * F + f] = v;
+        s1 += v * fold_out[p * F + f];
+        s2 += v * fold_out[P * F + p * F + f];
+    }
+#pragma unroll
+    for (int o = 1; o < P; o <<= 1) {     // the P heads of a row sit in consecutive lanes (P is a power of two)
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (live && p == 0) {
+        S2[r * 2] = s1;
+        S2[r * 2 + 1] = s2;
+    }
+}
+
+// out head of graph_goals (concat=False) + eval BatchNorm + tanh (gat_model.py:18-22), one workgroup per
+// (sample, scene):  out_i = tanh(scale * sum_j a_ij B_j + shift), written to columns [dst_col0, dst_col0 + G) of A1
+__global__ __launch_bounds__(256) void attn_out_kernel(int N, int S, const int32_t *__restrict__ scene_ptr,
+                                                       const int64_t *__restrict__ off_compact, int64_t compact,
+                                                       const float *__restrict__ adj, const float *__restrict__ S2, float alpha,
+                                                       const float *__restrict__ B, int64_t ldb, int G,
+                                                       const float *__restrict__ bn, float *__restrict__ out, int64_t ldo) {
+    __shared__ float att[32][33];
+    const int u = blockIdx.x, k = u / S, s = u - k * S;
+    const int b = scene_ptr[s], n = scene_ptr[s + 1] - b;      // n <= 32 (checked by the host)
+    const int64_t r0 = (int64_t)k * N + b;
+    const float *ablk = adj + (int64_t)k * compact + off_compact[s];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * n; e += 256) {
+        const int i = e / n, j = e - i * n;
+        const float v = S2[(r0 + i) * 2] + S2[(r0 + j) * 2 + 1];
+        att[i][j] = ablk[e] > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
+    }
+    __syncthreads();
+    if (tid < n) {
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j) mx = fmaxf(mx, att[tid][j]);
+        float sum = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float w = att[tid][j] == -INFINITY ? 0.f : expf(att[tid][j] - mx);
+            att[tid][j] = w;
+            sum += w;
+        }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < n; ++j) att[tid][j] *= inv;
+    }
+    __syncthreads();
+    const int G4 = G >> 2;                                       // G is a multiple of 4 (checked by the host)
+    for (int c4 = tid; c4 < G4; c4 += 256) {
+        const float4 sc = *reinterpret_cast<const float4 *>(bn + c4 * 4);
+        const float4 sh = *reinterpret_cast<const float4 *>(bn + G + c4 * 4);
+        for (int i0 = 0; i0 < n; i0 += 8) {
+            float4 acc[8];
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii) acc[ii] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < n; ++j) {
+                const float4 bj = *reinterpret_cast<const float4 *>(B + (r0 + j) * ldb + c4 * 4);
+#pragma unroll
+                for (int ii = 0; ii < 8; ++ii) {
+                    const float w = att[min(i0 + ii, 31)][j];
+                    acc[ii].x += w * bj.x; acc[ii].y += w * bj.y; acc[ii].z += w * bj.z; acc[ii].w += w * bj.w;
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 8; ++ii)
+                if (i0 + ii < n) {
+                    float4 o;
+                    o.x = tanhf(acc[ii].x * sc.x + sh.x); o.y = tanhf(acc[ii].y * sc.y + sh.y);
+                    o.z = tanhf(acc[ii].z * sc.z + sh.z); o.w = tanhf(acc[ii].w * sc.w + sh.w);
+                    *reinterpret_cast<float4 *>(out + (r0 + i0 + ii) * ldo + c4 * 4) = o;
+                }
+        }
+    }
+}
+
+// categorical draw of the goal (utils.py:200-207 via multinomial == argmax p/q, q ~ Exp(1)); one wave per row.
+// The reference feeds exp(softmax probabilities) to multinomial (models/dagnet/model.py:232-233).
+__global__ void draw_kernel(int N, int K, int T, int t, int G, const float *__restrict__ LG, int64_t ld, const float *__restrict__ q,
+                            uint64_t seed, const int32_t *__restrict__ force_goals, int32_t *__restrict__ goal,
+                            int32_t *__restrict__ out_goals) {
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= (int64_t)N * K) return;
+    const int lane = threadIdx.x & 63;
+    const int g = (int)(r % N), k = (int)(r / N);
+    const float *p = LG + r * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < G; c += 64) mx = fmaxf(mx, p[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < G; c += 64) s += expf(p[c] - mx);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    const int64_t slot = ((int64_t)k * T + t) * N + g;
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < G; c += 64) {
+        const float qq = q ? q[slot * G + c] : rng_exp1(seed, (uint32_t)r, (uint32_t)t, (uint32_t)c);
+        const float v = expf(expf(p[c] - mx) * inv) / qq;
+        if (v > best) { best = v; bi = c; }            // c increases: the first maximum of the lane wins
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        if (force_goals) bi = force_goals[slot];
+        bi = min(max(bi, 0), G - 1);
+        goal[r] = bi;
+        if (out_goals) out_goals[slot] = bi;
+    }
+}
+
+}   // namespace wide
+
+struct WideStep {
+    const float *wp;                  // model weight buffer
+    WideWeights w;
+    WideBuffers b;
+    const int32_t *scene_ptr, *row_scene;
+    const int64_t *off_compact;
+    int64_t compact;
+    int N, K, S, T, t;
+    int D, R, H, G, L, P, F;
+    int adj_type, top_k;
+    double sigma;
+    float alpha;
+    const float *q;
+    const int32_t *force_goals;
+    uint64_t seed;
+    int32_t *out_goals;
+};
+
+#define W_TRY(x)                           \
+    do {                                   \
+        hipError_t e_ = (x);               \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+
+extern "C" hipError_t dn_wide_init_state(int N, int K, int L, int R, int G, const float *h0, const float *x0, const int32_t *g0,
+                                         float *h, float *pos, int32_t *goal, hipStream_t st) {
+    const int64_t total = (int64_t)L * N * K * R;
+    hipLaunchKernelGGL(wide::init_state_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, N, K, L, R, G, h0, x0, g0, h,
+                       pos, goal);
+    return hipGetLastError();
+}
+
+// goal head of step s.t for all K*N rows: reads the state (h of the last layer, positions, previous goals), writes the new
+// goals into the goal state (and out_goals)
+extern "C" hipError_t dn_wide_goal_head(const WideStep *sp, hipStream_t st) {
+    const WideStep &s = *sp;
+    const int64_t rows64 = (int64_t)s.N * s.K;
+    if (rows64 > 0x7fffffffLL) return hipErrorInvalidValue;
+    const int rows = (int)rows64;
+    const int PF = s.P * s.F;
+    const int64_t Gp = s.b.Gp;
+    const float *hl = s.b.h + (int64_t)(s.L - 1) * rows * s.R;
+    // adjacency of every sample from the PRE-update positions (models/dagnet/model.py:215-220)
+    W_TRY(dn_launch_adjacency(s.adj_type, s.sigma, s.top_k, s.scene_ptr, s.row_scene, s.off_compact, s.N, s.K, s.b.pos, s.b.adj, 0,
+                              s.compact, st));
+    {
+        const int64_t total = rows64 * s.b.a0_ld;
+        hipLaunchKernelGGL(wide::goal_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s.N, s.K, s.D, s.R, s.b.a0_ld,
+                           s.scene_ptr, s.row_scene, s.b.pos, hl, s.b.A0);
+        W_TRY(hipGetLastError());
+    }
+    W_TRY(dn_gemm_nt_gather(s.b.A0, s.b.a0_ld, s.wp + s.w.g0_w, s.w.g0_ld, s.wp + s.w.g0_b, s.b.T1, s.H, rows, s.H, (int)s.b.a0_ld,
+                            wide::ACT_RELU, 0.f, s.wp + s.w.g0_gather, s.b.goal, s.w.g0_gld, st));
+    W_TRY(dn_gemm_nt_gather(s.b.T1, s.H, s.wp + s.w.g2_w, s.w.g2_ld, s.wp + s.w.g2_b, s.b.A1, 2 * Gp, rows, s.G, s.w.g2_ld,
+                            wide::ACT_NONE, 0.f, nullptr, nullptr, 0, st));
+    hipLaunchKernelGGL(wide::softmax_kernel, dim3((unsigned)((rows64 + 3) / 4)), dim3(256), 0, st, rows64, s.G, 2 * Gp, s.b.A1);
+    W_TRY(hipGetLastError());
+    W_TRY(dn_gemm_nt_gather(s.b.A1, 2 * Gp, s.wp + s.w.hf_w, s.w.hf_ld, nullptr, s.b.HS, s.b.hs_ld, rows, PF + 2 * s.P, (int)Gp,
+                            wide::ACT_NONE, 0.f, nullptr, nullptr, 0, st));
+    if (s.P != 4 || s.F != 8) return hipErrorInvalidValue;
+    {
+        const int64_t total = rows64 * s.P;
+        hipLaunchKernelGGL((wide::attn_heads_kernel<4, 8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s.N, s.K,
+                           s.scene_ptr, s.row_scene, s.off_compact, s.compact, s.b.adj, s.b.HS, s.b.hs_ld, s.wp + s.w.fold_out,
+                           s.alpha, s.b.X2, s.b.S2);
+        W_TRY(hipGetLastError());
+    }
+    W_TRY(dn_gemm_nt_gather(s.b.X2, PF, s.wp + s.w.out_w, s.w.out_ld, nullptr, s.b.B, Gp, rows, s.G, PF, wide::ACT_NONE, 0.f,
+                            nullptr, nullptr, 0, st));
+    hipLaunchKernelGGL(wide::attn_out_kernel, dim3((unsigned)(s.K * s.S)), dim3(256), 0, st, s.N, s.S, s.scene_ptr, s.off_compact,
+                       s.compact, s.b.adj, s.b.S2, s.alpha, s.b.B, Gp, s.G, s.wp + s.w.bn, s.b.A1 + Gp, 2 * Gp);
+    W_TRY(hipGetLastError());
+    W_TRY(dn_gemm_nt_gather(s.b.A1, 2 * Gp, s.wp + s.w.lg_w, s.w.lg_ld, s.wp + s.w.lg_b, s.b.B, Gp, rows, s.G, (int)(2 * Gp),
+                            wide::ACT_NONE, 0.f, nullptr, nullptr, 0, st));
+    hipLaunchKernelGGL(wide::draw_kernel, dim3((unsigned)((rows64 + 3) / 4)), dim3(256), 0, st, s.N, s.K, s.T, s.t, s.G, s.b.B, Gp, s.q,
+                       s.seed, s.force_goals, s.b.goal, s.out_goals);
+    return hipGetLastError();
+}

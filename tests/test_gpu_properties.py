@@ -261,7 +261,7 @@ def test_errors_are_loud():
     ("avrnn_sdd_gat", "register-resident"), ("vrnn_sdd", "register-resident"), ("avrnn_bsk_gat_L2_n10", "register-resident"),
     ("dagnet_bsk_gat_ragged_1_32", "LDS-tiled"),      # n_max_agents = 32 > 16: disposition wider than one k-tile
     ("avrnn_bsk_gat_n33", "LDS-tiled"),               # a 33-agent scene does not fit a 32-row wave tile
-    ("dagnet_bsk_gcn_n10", "LDS-tiled"), ("dagnet_tiny_gat_adj1", "LDS-tiled"), ("dagnet_sdd_gat_g960", "global scratch"),
+    ("dagnet_bsk_gcn_n10", "LDS-tiled"), ("dagnet_tiny_gat_adj1", "LDS-tiled"), ("dagnet_sdd_gat_g960", "wide goal head"), ("dagnet_sdd_gcn_g960", "global scratch"),
 ])
 def test_kernel_dispatch(name, want):
     """Which kernel a golden case runs on (the parity tests cover both kernels only if the dispatch is as intended)."""

@@ -91,8 +91,13 @@ def _gru_step(sd, x, h, n_layers):
     return torch.stack(out, 0)
 
 
+_BN_HOOK = []      # train_step() records the BatchNorm inputs here (running-statistics update)
+
+
 def _bn_eval(sd, prefix, x, training=False, eps=1e-5):
     if training:
+        for hook in _BN_HOOK:
+            hook(prefix, x)
         mu = x.mean(0)
         var = x.var(0, unbiased=False)
     else:
@@ -426,3 +431,63 @@ def evaluate_best_of_k(samples_rel_k, start, gt, sse):
         ades.append(ade_raw(a, gt))
         fdes.append(fde_raw(a[-1], gt[-1]))
     return min_over_k_sum(torch.stack(ades), sse), min_over_k_sum(torch.stack(fdes), sse)
+
+
+# --------------------------------------------------------------------------
+# one training step (row T): models/dagnet/train_bsk.py:259-291, models/avrnn/train_bsk.py:231-262,
+# models/baseline/train_bsk.py (same three lines without the graph)
+# --------------------------------------------------------------------------
+def train_step(sd, cfg, kind, batch, eps, kld_weight=1.0, ce_weight=1.0, lr=1e-3, clip=10.0, adam_state=None):
+    """Train-mode forward (BatchNorm batch statistics), loss = kld_weight KLD + NLL (+ ce_weight CE), backward,
+    clip_grad_norm_(clip), one Adam step (torch.optim.Adam defaults: betas (0.9, 0.999), eps 1e-8, no weight decay).
+
+    batch: VRNN (x_rel,), A-VRNN (x_rel, adj[T,N,N]), DAG-Net (traj, traj_rel, goals_ohe, sse, adj).
+    -> dict(kld, nll, ce, loss, grads{name}, total_norm, params{name} after the step, buffers{name} after the step)
+    BatchNorm running statistics follow nn.BatchNorm1d (momentum 0.1, unbiased variance, one update per call)."""
+    params = {k: v.detach().clone().requires_grad_(True) for k, v in sd.items() if v.dtype.is_floating_point and "running_" not in k}
+    work = dict(sd)
+    work.update(params)
+    bn_inputs = []
+
+    def bn_train_hook(prefix, x):
+        bn_inputs.append((prefix, x.detach()))
+    _BN_HOOK.append(bn_train_hook)
+    try:
+        if kind == "vrnn":
+            kld, nll, _ = vrnn_forward(work, cfg, batch[0], eps)
+            ce = torch.zeros(1)
+            loss = kld_weight * kld + nll
+        elif kind == "avrnn":
+            kld, nll, _ = avrnn_forward(work, cfg, batch[0], batch[1], eps, training=True)
+            ce = torch.zeros(1)
+            loss = kld_weight * kld + nll
+        else:
+            kld, nll, ce, _ = dagnet_forward(work, cfg, *batch, eps, training=True)
+            loss = kld_weight * kld + nll + ce_weight * ce
+    finally:
+        _BN_HOOK.pop()
+    names = list(params)
+    grads = torch.autograd.grad(loss.sum(), [params[k] for k in names], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(params[k])) for k, g in zip(names, grads)}
+    total_norm = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).float()
+    coef = torch.clamp(clip / (total_norm + 1e-6), max=1.0)
+    b1, b2, aeps = 0.9, 0.999, 1e-8
+    step = 1 if adam_state is None else adam_state["step"] + 1
+    new_params, m_out, v_out = {}, {}, {}
+    for k in names:
+        g = grads[k] * coef
+        m = (adam_state["m"][k] if adam_state else torch.zeros_like(g)) * b1 + (1 - b1) * g
+        v = (adam_state["v"][k] if adam_state else torch.zeros_like(g)) * b2 + (1 - b2) * g * g
+        denom = v.sqrt() / math.sqrt(1 - b2 ** step) + aeps
+        new_params[k] = params[k].detach() - (lr / (1 - b1 ** step)) * m / denom
+        m_out[k], v_out[k] = m, v
+    buffers = {k: v.clone() for k, v in sd.items() if k not in params}
+    for prefix, x in bn_inputs:
+        n = x.shape[0]
+        buffers[prefix + ".running_mean"] = 0.9 * buffers[prefix + ".running_mean"] + 0.1 * x.mean(0)
+        buffers[prefix + ".running_var"] = 0.9 * buffers[prefix + ".running_var"] + 0.1 * x.var(0, unbiased=True) if n > 1 \
+            else buffers[prefix + ".running_var"]
+        if prefix + ".num_batches_tracked" in buffers:
+            buffers[prefix + ".num_batches_tracked"] = buffers[prefix + ".num_batches_tracked"] + 1
+    return dict(kld=kld.detach(), nll=nll.detach(), ce=ce.detach(), loss=loss.detach(), grads=grads, total_norm=total_norm,
+                params=new_params, buffers=buffers, adam=dict(step=step, m=m_out, v=v_out))

@@ -157,6 +157,59 @@ def build_case(name, kind, args_kw, sizes, obs_len, pred_len, seed, K, data_kind
           f"ade_sum={float(out['ade_sum']):.4f}" + (f" min_margin={float(np.min(out['margins'])):.2e}" if goals else ""))
 
 
+def train_case(name, kind, args_kw, sizes, obs_len, pred_len, seed, kld_weight=0.5, ce_weight=1e-2, lr=1e-3, clip=10.0,
+               data_kind="bsk", g_cells=(9, 10)):
+    """One training step exactly as the reference issues it (models/dagnet/train_bsk.py:259-291 and the avrnn /
+    baseline analogues): model.train(), forward on the full sequence (DAG-Net) or the observed steps (others),
+    loss = w_kld KLD + NLL (+ CE_weight CE), backward, clip_grad_norm_(params, clip), Adam step.
+    Stored: losses, every parameter's .grad, the total norm, the parameters and BatchNorm buffers after the step."""
+    args = syn.make_args(obs_len=obs_len, pred_len=pred_len, **args_kw)
+    n_max = int(max(sizes))
+    ref = RefVRNN(args) if kind == "vrnn" else RefAVRNN(args) if kind == "avrnn" else RefDAGNet(args, n_max)
+    sd = syn.random_state_dict(ref, seed)
+    ref.load_state_dict(sd)
+    ref.train()
+    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = syn.make_batch(sizes, obs_len, pred_len, seed, kind=data_kind, g_cells=g_cells)
+    N = obs.shape[1]
+    T = obs_len + pred_len if kind == "dagnet" else obs_len
+    eps = syn.uniform_noise(seed, "eps_train", (T - 1, N, args.z_dim))
+    opt = torch.optim.Adam(ref.parameters(), lr=lr)
+    opt.zero_grad()
+    with Injector() as inj:
+        inj.eps = [eps[t] for t in range(T - 1)]
+        if kind == "vrnn":
+            kld, nll, _ = ref(obs_rel)
+            ce = torch.zeros(1)
+            loss = kld_weight * kld + nll
+        elif kind == "avrnn":
+            kld, nll, _ = ref(obs_rel, _ref_obs_adj(args, sse, obs, gt))
+            ce = torch.zeros(1)
+            loss = kld_weight * kld + nll
+        else:
+            adj = _ref_obs_adj(args, sse, obs, gt)
+            traj, rel = torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0)
+            g_ohe = torch.cat((ref_utils.to_goals_one_hot(obs_goals, args.g_dim), ref_utils.to_goals_one_hot(gt_goals, args.g_dim)), 0)
+            kld, nll, ce, _ = ref(traj, rel, g_ohe, sse, adj)
+            loss = kld_weight * kld + nll + ce * ce_weight
+        assert not inj.eps
+    loss.backward()
+    out = dict(kld=kld.detach().numpy(), nll=nll.detach().numpy(), ce=ce.detach().numpy(), loss=loss.detach().numpy())
+    for k_, p_ in ref.named_parameters():
+        out["grad/" + k_] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy().copy()
+    total_norm = torch.nn.utils.clip_grad_norm_(ref.parameters(), clip)
+    out["total_norm"] = np.float32(total_norm)
+    opt.step()
+    for k_, v in ref.state_dict().items():
+        out["after/" + k_] = v.detach().numpy().copy()
+    meta = dict(name=name, kind=kind, args=args_kw, sizes=[int(s_) for s_ in sizes], obs_len=obs_len, pred_len=pred_len, seed=seed,
+                data_kind=data_kind, g_cells=list(g_cells), n_max_agents=n_max, kld_weight=kld_weight, ce_weight=ce_weight, lr=lr,
+                clip=clip, checks=dict(obs=checksum(obs), eps=checksum(eps),
+                                       weights=float(sum(checksum(v) for v in sd.values() if v.dtype.is_floating_point))))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: N={N} T={T} kld={float(kld):.5f} nll={float(nll):.5f} ce={float(ce):.5f} |g|={float(total_norm):.4f}")
+
+
 def _ref_obs_adj(args, sse, obs, gt):
     if args.adjacency_type == 0:
         return ref_adj.compute_adjs(args, sse)
@@ -212,9 +265,24 @@ TINY = dict(h_dim=16, z_dim=8, rnn_dim=16, g_dim=12)
 REAL = dict(h_dim=64, z_dim=32, rnn_dim=64, g_dim=90)
 
 
+def train_cases():
+    # --- one training step (row T): tiny dims for every model / graph kind, one real-dims DAG-Net step
+    train_case("train_vrnn_tiny", "vrnn", dict(TINY, n_layers=2), [2, 5, 3], 4, 5, 60)
+    train_case("train_avrnn_tiny_gat", "avrnn", dict(TINY, n_layers=1, graph_model="gat", adjacency_type=1), [2, 5, 3], 4, 5, 61)
+    train_case("train_avrnn_tiny_gcn", "avrnn", dict(TINY, n_layers=2, graph_model="gcn", adjacency_type=2, top_k_neigh=3), [2, 5, 3], 4, 5, 62)
+    train_case("train_dagnet_tiny_gat", "dagnet", dict(TINY, n_layers=2, graph_model="gat", adjacency_type=1), [2, 5, 3], 4, 5, 63,
+               g_cells=(3, 4), data_kind="sdd")
+    train_case("train_dagnet_tiny_gcn", "dagnet", dict(TINY, n_layers=1, graph_model="gcn", adjacency_type=0), [2, 5, 3], 4, 5, 64,
+               g_cells=(3, 4), data_kind="sdd")
+    train_case("train_dagnet_bsk_gat_n5", "dagnet", dict(REAL, n_layers=2), [5, 5, 5], 3, 4, 65)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "train":
+        return train_cases()
     state_dict_layouts()
+    train_cases()
     # --- tiny dims, ragged scenes, every graph x adjacency combination
     for L in (1, 2):
         build_case(f"vrnn_tiny_L{L}", "vrnn", dict(TINY, n_layers=L), [2, 5, 3], 4, 5, 10 + L, 2)

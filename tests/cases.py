@@ -78,3 +78,24 @@ DISP_ATOL, DISP_RTOL = 1e-4, 1e-4        # per-step displacements
 H_ATOL = 2e-4                             # hidden state after the observed steps
 LOSS_RTOL = 1e-4                          # KLD / NLL / CE, ADE / FDE sums
 MARGIN_MIN = 1e-4                         # rows whose top-2 goal margin is below this are excluded
+
+
+# ---- training-step fixtures (row T) ---------------------------------------------------------------
+def list_train_cases():
+    return list_cases(("train_",))
+
+
+GRAD_RTOL = 2e-4          # per-parameter gradient: |got - want| <= GRAD_RTOL * max|want| + GRAD_ATOL
+GRAD_ATOL = 2e-6
+
+
+def build_train_inputs(meta):
+    """-> (batch tuple as seq_collate emits it, eps [T-1,N,Z]); T = full sequence for DAG-Net, observed steps otherwise."""
+    seed = meta["seed"]
+    batch = syn.make_batch(meta["sizes"], meta["obs_len"], meta["pred_len"], seed, kind=meta["data_kind"], g_cells=tuple(meta["g_cells"]))
+    N = batch[0].shape[1]
+    T = meta["obs_len"] + meta["pred_len"] if meta["kind"] == "dagnet" else meta["obs_len"]
+    eps = syn.uniform_noise(seed, "eps_train", (T - 1, N, meta["args"]["z_dim"]))
+    c = meta["checks"]
+    assert abs(_sum(batch[0]) - c["obs"]) <= 1e-9 * max(1.0, abs(c["obs"])) and abs(_sum(eps) - c["eps"]) <= 1e-9 * max(1.0, abs(c["eps"]))
+    return batch, eps

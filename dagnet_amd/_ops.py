@@ -1,0 +1,563 @@
+"""Differentiable operators of the training step (row T), each a torch.autograd.Function whose forward and backward
+are HIP kernels behind the C ABI (dagnet_op_* in include/dagnet_hip.h: fp32 MFMA GEMMs of csrc/gemm_f32.hip, row-wise
+and per-scene kernels of csrc/train_ops.hip).  torch allocates the buffers and runs the autograd tape; no torch
+arithmetic happens in here.  There is no CPU path: every tensor must live on a ROCm device.
+
+All matrices are 2-D fp32 with unit column stride; a row-strided view (a column slice of a wider matrix) is passed as
+(pointer, row stride) without a copy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from . import _capi
+from ._capi import DagnetHipError, _check, _stream
+
+ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
+
+OP_EXPORTS = (
+    "dagnet_op_gemm", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_act_bwd", "dagnet_op_copy2d",
+    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd",
+    "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
+    "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
+    "dagnet_op_gat_attn_fwd", "dagnet_op_gat_attn_bwd", "dagnet_op_adj_matmul", "dagnet_op_disposition", "dagnet_op_sumsq",
+    "dagnet_op_adam",
+)
+
+_bound = False
+
+
+def _lib():
+    global _bound
+    lib = _capi.load()
+    if not _bound:
+        vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+        lib.dagnet_op_gemm.argtypes = [vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, f32, i32, vp, vp, i64, i64, vp]
+        lib.dagnet_op_gemm_tn_workspace.argtypes = [i32, i32, i32]
+        lib.dagnet_op_gemm_tn_workspace.restype = i64
+        lib.dagnet_op_gemm_tn.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, vp]
+        lib.dagnet_op_act_bwd.argtypes = [i64, i32, vp, i64, vp, i64, vp, i64, i32, f32, vp]
+        lib.dagnet_op_copy2d.argtypes = [i64, i32, vp, i64, vp, i64, i32, vp]
+        lib.dagnet_op_onehot_grad.argtypes = [i64, i32, vp, i64, vp, vp, i64, vp]
+        lib.dagnet_op_softmax_fwd.argtypes = [i64, i32, vp, i64, vp, i64, vp]
+        lib.dagnet_op_softmax_bwd.argtypes = [i64, i32, vp, i64, vp, i64, vp, i64, vp]
+        lib.dagnet_op_gru_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp]
+        lib.dagnet_op_gru_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.dagnet_op_vae_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.dagnet_op_vae_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp]
+        lib.dagnet_op_nll_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp]
+        lib.dagnet_op_nll_bwd.argtypes = [i64, i32, vp, vp, vp, vp, f32, vp, vp, vp]
+        lib.dagnet_op_ce_fwd.argtypes = [i64, vp, i64, vp, vp, vp]
+        lib.dagnet_op_ce_bwd.argtypes = [i64, i32, vp, vp, vp, i64, vp]
+        lib.dagnet_op_sum.argtypes = [i64, vp, f32, vp, i32, vp]
+        lib.dagnet_op_col_workspace.argtypes = [i64, i32]
+        lib.dagnet_op_col_workspace.restype = i64
+        lib.dagnet_op_colsum.argtypes = [i64, i32, vp, i64, vp, i32, vp, vp]
+        lib.dagnet_op_bn_fwd.argtypes = [i64, i32, vp, i64, vp, vp, f32, f32, i32, vp, i64, vp, vp, vp, vp, vp, vp]
+        lib.dagnet_op_bn_bwd.argtypes = [i64, i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, vp, i64, vp, vp, i32, vp, vp, vp]
+        lib.dagnet_op_gat_attn_fwd.argtypes = [vp, vp, i64, vp, i64, vp, i32, i32, f32, i32, vp, i64, vp]
+        lib.dagnet_op_gat_attn_bwd.argtypes = [vp, vp, i64, vp, i64, vp, i32, i32, f32, i32, vp, i64, vp, i64, vp, i64, vp, vp]
+        lib.dagnet_op_adj_matmul.argtypes = [vp, i32, vp, i64, vp, i64, vp, i32, vp, i64, vp]
+        lib.dagnet_op_disposition.argtypes = [vp, i32, vp, vp, i64, vp]
+        lib.dagnet_op_sumsq.argtypes = [i64, vp, vp, vp]
+        lib.dagnet_op_adam.argtypes = [i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, vp]
+        _bound = True
+    return lib
+
+
+# ---------------------------------------------------------------------------------------------
+# plumbing
+# ---------------------------------------------------------------------------------------------
+_scratch: Dict[torch.device, torch.Tensor] = {}
+
+
+def _ws(device, nfloats: int) -> torch.Tensor:
+    """Per-device scratch (split-reduction partials).  Kernels of one stream run in order, so one buffer is enough."""
+    t = _scratch.get(device)
+    if t is None or t.numel() < nfloats:
+        t = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
+        _scratch[device] = t
+    return t
+
+
+def _m(t: torch.Tensor, what="operand"):
+    """-> (pointer, row stride) of a 2-D fp32 device matrix with unit column stride."""
+    if not t.is_cuda or t.dtype != torch.float32:
+        raise DagnetHipError(f"{what} must be an fp32 tensor on a ROCm device (got {t.dtype} on {t.device}); there is no CPU path")
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise DagnetHipError(f"{what} must be 2-D with unit column stride (got shape {tuple(t.shape)}, strides {t.stride()})")
+    ld = t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+    return C.c_void_p(t.data_ptr()), int(ld)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _adj_ld(adj: torch.Tensor) -> int:
+    """Adjacency of one timestep: compact block-diagonal values (1-D) -> 0, dense [N, N] -> N."""
+    if adj.dim() == 1:
+        return 0
+    if adj.dim() == 2 and adj.shape[0] == adj.shape[1] and adj.is_contiguous():
+        return int(adj.shape[0])
+    raise DagnetHipError(f"adjacency must be compact (1-D) or a contiguous dense [N, N] matrix, got shape {tuple(adj.shape)}")
+
+
+def _rows(t: torch.Tensor) -> torch.Tensor:
+    """A gradient as autograd hands it over -> usable matrix (expanded / non-unit-stride grads are materialised by our copy)."""
+    if t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1) and (t.shape[0] <= 1 or t.stride(0) >= t.shape[1]):
+        return t
+    return t.contiguous()
+
+
+def gemm(A, B, C_out, *, transb=False, bias=None, act=ACT_NONE, slope=0.01, accumulate=False, gather=None, gidx=None, gs_g=0, gs_n=0,
+         K=None):
+    """C = act([C +] A op(B) + bias + gather[gidx]) ;  op(B) = B^T for B [N,K] (nn.Linear), B for B [K,N] when transb."""
+    (a, lda), (b, ldb), (c, ldc) = _m(A, "A"), _m(B, "B"), _m(C_out, "C")
+    M, N = C_out.shape
+    K = A.shape[1] if K is None else K
+    _check(_lib().dagnet_op_gemm(a, lda, b, ldb, int(transb), _p(bias), c, ldc, M, N, K, act, slope, int(accumulate),
+                                 gather, _p(gidx), gs_g, gs_n, _stream(A.device)))
+
+
+def gemm_tn(A, B, C_out, accumulate=False):
+    """C[N,K] (+)= A[M,N]^T B[M,K]"""
+    (a, lda), (b, ldb), (c, ldc) = _m(A, "A"), _m(B, "B"), _m(C_out, "C")
+    M, N, K = A.shape[0], A.shape[1], B.shape[1]
+    ws = _ws(A.device, _lib().dagnet_op_gemm_tn_workspace(M, N, K))
+    _check(_lib().dagnet_op_gemm_tn(a, lda, b, ldb, c, ldc, M, N, K, _p(ws), int(accumulate), _stream(A.device)))
+
+
+def colsum(X, out, accumulate=False):
+    (x, ldx) = _m(X, "X")
+    M, N = X.shape
+    ws = _ws(X.device, _lib().dagnet_op_col_workspace(M, N))
+    _check(_lib().dagnet_op_colsum(M, N, x, ldx, _p(out), int(accumulate), _p(ws), _stream(X.device)))
+
+
+def copy2d(src, dst, accumulate=False):
+    (s, lds), (d, ldd) = _m(src, "src"), _m(dst, "dst")
+    _check(_lib().dagnet_op_copy2d(src.shape[0], src.shape[1], s, lds, d, ldd, int(accumulate), _stream(src.device)))
+
+
+def _empty(M, N, like):
+    return torch.empty((M, N), dtype=torch.float32, device=like.device)
+
+
+# ---------------------------------------------------------------------------------------------
+# dense layers
+# ---------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = act(sum_s x_s W[:, c_s : c_s + K_s]^T + b + W[:, gcol + gidx])  -- an nn.Linear whose input is the
+    concatenation of dense pieces and (optionally) one one-hot piece given by its index (never materialised)."""
+
+    @staticmethod
+    def forward(ctx, W, b, act, slope, cols, gidx, gcol, *xs):
+        N, Ktot = W.shape
+        M = xs[0].shape[0]
+        y = _empty(M, N, xs[0])
+        last = len(xs) - 1
+        for s, (x, c0) in enumerate(zip(xs, cols)):
+            Ks = x.shape[1]
+            Wp = W[:, c0:c0 + Ks]
+            fin = s == last
+            if fin and gidx is not None:
+                gemm(x, Wp, y, bias=b, act=act, slope=slope, accumulate=s > 0,
+                     gather=C.c_void_p(W.data_ptr() + 4 * gcol), gidx=gidx, gs_g=1, gs_n=Ktot)
+            else:
+                gemm(x, Wp, y, bias=b if fin else None, act=act if fin else ACT_NONE, slope=slope, accumulate=s > 0)
+        ctx.save_for_backward(W, y, gidx, *xs)
+        ctx.meta = (act, slope, tuple(cols), gcol, b is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        W, y, gidx, *xs = ctx.saved_tensors
+        act, slope, cols, gcol, has_b = ctx.meta
+        N, Ktot = W.shape
+        M = y.shape[0]
+        dy = _rows(dy)
+        if act != ACT_NONE:
+            dpre = _empty(M, N, y)
+            (g, ldg), (yy, ldy), (dp, ldp) = _m(dy), _m(y), _m(dpre)
+            _check(_lib().dagnet_op_act_bwd(M, N, g, ldg, yy, ldy, dp, ldp, act, slope, _stream(y.device)))
+        else:
+            dpre = dy
+        dW = db = None
+        if ctx.needs_input_grad[0]:
+            dW = torch.zeros_like(W)
+            for x, c0 in zip(xs, cols):
+                gemm_tn(dpre, x, dW[:, c0:c0 + x.shape[1]])
+            if gidx is not None:
+                (dp, ldp) = _m(dpre)
+                _check(_lib().dagnet_op_onehot_grad(M, N, dp, ldp, _p(gidx), C.c_void_p(dW.data_ptr() + 4 * gcol), Ktot,
+                                                    _stream(y.device)))
+        if has_b and ctx.needs_input_grad[1]:
+            db = torch.empty(N, dtype=torch.float32, device=y.device)
+            colsum(dpre, db)
+        dxs = []
+        for i, (x, c0) in enumerate(zip(xs, cols)):
+            if ctx.needs_input_grad[7 + i]:
+                dx = _empty(M, x.shape[1], y)
+                gemm(dpre, W[:, c0:c0 + x.shape[1]], dx, transb=True, K=N)
+                dxs.append(dx)
+            else:
+                dxs.append(None)
+        return (dW, db, None, None, None, None, None, *dxs)
+
+
+def linear(mod, xs: Sequence[torch.Tensor], cols: Sequence[int], act=ACT_NONE, slope=0.01, gidx=None, gcol=0):
+    """nn.Linear ``mod`` applied to [x_0 | ... | one-hot(gidx)] with x_s at input columns cols[s] and the one-hot block at gcol."""
+    return LinearFn.apply(mod.weight, mod.bias, act, slope, tuple(cols), gidx, gcol, *xs)
+
+
+class MatmulFn(torch.autograd.Function):
+    """x @ W with W [K,N] (the graph layers store their weights input-major)."""
+
+    @staticmethod
+    def forward(ctx, x, W):
+        y = _empty(x.shape[0], W.shape[1], x)
+        gemm(x, W, y, transb=True)
+        ctx.save_for_backward(x, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = _rows(dy)
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            dx = _empty(x.shape[0], x.shape[1], x)
+            gemm(dy, W, dx)                       # dy [M,N] . W[K,N]^T
+        if ctx.needs_input_grad[1]:
+            dW = torch.empty_like(W)
+            gemm_tn(x, dy, dW)
+        return dx, dW
+
+
+class StackFn(torch.autograd.Function):
+    """[W_0 | W_1 | ...] along the columns (the heads of a GAT evaluated as one GEMM), or flattened row vectors stacked
+    along the rows when ``rows`` (the attention vectors a_p [2F,1] -> [P, 2F])."""
+
+    @staticmethod
+    def forward(ctx, rows, *ws):
+        if rows:
+            n = ws[0].numel()
+            out = _empty(len(ws), n, ws[0])
+            for i, w in enumerate(ws):
+                copy2d(w.view(1, n), out[i:i + 1])
+        else:
+            K, F = ws[0].shape
+            out = _empty(K, F * len(ws), ws[0])
+            for i, w in enumerate(ws):
+                copy2d(w, out[:, i * F:(i + 1) * F])
+        ctx.rows = rows
+        ctx.shapes = [tuple(w.shape) for w in ws]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = _rows(dout)
+        grads = []
+        for i, shp in enumerate(ctx.shapes):
+            g = torch.empty(shp, dtype=torch.float32, device=dout.device)
+            if ctx.rows:
+                copy2d(dout[i:i + 1], g.view(1, -1))
+            else:
+                F = shp[1]
+                copy2d(dout[:, i * F:(i + 1) * F], g)
+            grads.append(g)
+        return (None, *grads)
+
+
+class SoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        y = torch.empty_like(x)
+        (xp, ldx), (yp, ldy) = _m(x), _m(y)
+        _check(_lib().dagnet_op_softmax_fwd(x.shape[0], x.shape[1], xp, ldx, yp, ldy, _stream(x.device)))
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _rows(dy)
+        dx = torch.empty_like(y)
+        (yp, ldy), (gp, ldg), (xp, ldx) = _m(y), _m(dy), _m(dx)
+        _check(_lib().dagnet_op_softmax_bwd(y.shape[0], y.shape[1], yp, ldy, gp, ldg, xp, ldx, _stream(y.device)))
+        return dx
+
+
+class GruCellFn(torch.autograd.Function):
+    """h' from gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh (nn.GRU gate order r, z, n)."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h):
+        M, R = h.shape
+        hn = torch.empty_like(h)
+        gates = _empty(M, 3 * R, h)
+        _check(_lib().dagnet_op_gru_fwd(M, R, _p(gi), _p(gh), _p(h), _p(hn), _p(gates), _stream(h.device)))
+        ctx.save_for_backward(gates, gh, h)
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        gates, gh, h = ctx.saved_tensors
+        M, R = h.shape
+        dhn = dhn.contiguous()
+        dgi, dgh, dh = _empty(M, 3 * R, h), _empty(M, 3 * R, h), torch.empty_like(h)
+        _check(_lib().dagnet_op_gru_bwd(M, R, _p(dhn), _p(gates), _p(gh), _p(h), _p(dgi), _p(dgh), _p(dh), _stream(h.device)))
+        return dgi, dgh, dh
+
+
+def _sum_rows(rows: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    out = torch.empty(1, dtype=torch.float32, device=rows.device)
+    _check(_lib().dagnet_op_sum(rows.numel(), _p(rows), scale, _p(out), 0, _stream(rows.device)))
+    return out
+
+
+class VaeFn(torch.autograd.Function):
+    """z = eps * exp(0.5 logvar_enc) + mean_enc and KLD(enc || prior), MEAN over the rows (models/dagnet/model.py:118-128)."""
+
+    @staticmethod
+    def forward(ctx, mu_e, lv_e, mu_p, lv_p, eps):
+        M, Z = mu_e.shape
+        z = torch.empty_like(mu_e)
+        rows = torch.empty(M, dtype=torch.float32, device=mu_e.device)
+        _check(_lib().dagnet_op_vae_fwd(M, Z, _p(mu_e), _p(lv_e), _p(mu_p), _p(lv_p), _p(eps), _p(z), _p(rows), _stream(mu_e.device)))
+        ctx.save_for_backward(mu_e, lv_e, mu_p, lv_p, eps)
+        return z, _sum_rows(rows, 1.0 / M)
+
+    @staticmethod
+    def backward(ctx, dz, dk):
+        mu_e, lv_e, mu_p, lv_p, eps = ctx.saved_tensors
+        M, Z = mu_e.shape
+        outs = [torch.empty_like(mu_e) for _ in range(4)]
+        dz = None if dz is None else dz.contiguous()
+        dk = None if dk is None else dk.contiguous()
+        _check(_lib().dagnet_op_vae_bwd(M, Z, _p(mu_e), _p(lv_e), _p(mu_p), _p(lv_p), _p(eps), _p(dz), _p(dk), 1.0 / M, *[_p(o) for o in outs],
+                                        _stream(mu_e.device)))
+        return (*outs, None)
+
+
+class NllFn(torch.autograd.Function):
+    """Gaussian negative log-likelihood, MEAN over the rows (models/dagnet/model.py:130-135)."""
+
+    @staticmethod
+    def forward(ctx, mu, lv, x):
+        M, X = mu.shape
+        rows = torch.empty(M, dtype=torch.float32, device=mu.device)
+        _check(_lib().dagnet_op_nll_fwd(M, X, _p(mu), _p(lv), _p(x), _p(rows), _stream(mu.device)))
+        ctx.save_for_backward(mu, lv, x)
+        return _sum_rows(rows, 1.0 / M)
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, lv, x = ctx.saved_tensors
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(lv)
+        _check(_lib().dagnet_op_nll_bwd(mu.shape[0], mu.shape[1], _p(mu), _p(lv), _p(x), _p(g.contiguous()), 1.0 / mu.shape[0], _p(dmu), _p(dlv),
+                                        _stream(mu.device)))
+        return dmu, dlv, None
+
+
+class CeFn(torch.autograd.Function):
+    """-sum_rows p[row, goal[row]]  (the reference's "cross entropy" on probabilities, models/dagnet/model.py:162)."""
+
+    @staticmethod
+    def forward(ctx, p, goal):
+        rows = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
+        (pp, ldp) = _m(p)
+        _check(_lib().dagnet_op_ce_fwd(p.shape[0], pp, ldp, _p(goal), _p(rows), _stream(p.device)))
+        ctx.save_for_backward(goal)
+        ctx.shape = tuple(p.shape)
+        return _sum_rows(rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        (goal,) = ctx.saved_tensors
+        M, G = ctx.shape
+        dp = torch.empty((M, G), dtype=torch.float32, device=goal.device)
+        _check(_lib().dagnet_op_ce_bwd(M, G, _p(goal), _p(g.contiguous()), _p(dp), G, _stream(goal.device)))
+        return dp, None
+
+
+# ---------------------------------------------------------------------------------------------
+# graph layers on the compact block-diagonal adjacency of a plan
+# ---------------------------------------------------------------------------------------------
+class GatAttnFn(torch.autograd.Function):
+    """Attention of one GAT layer for H heads of width F stacked along the columns of Wh (gat_layers.py:25-40)."""
+
+    @staticmethod
+    def forward(ctx, Wh, a, adj, plan, H, F, alpha, elu):
+        out = torch.empty_like(Wh)
+        (w, ldw), (o, ldo) = _m(Wh), _m(out)
+        _check(_lib().dagnet_op_gat_attn_fwd(plan._h, _p(adj), _adj_ld(adj), w, ldw, _p(a), H, F, alpha, int(elu), o, ldo, _stream(Wh.device)))
+        ctx.save_for_backward(Wh, a, adj, out)
+        ctx.meta = (plan, H, F, alpha, elu)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        Wh, a, adj, out = ctx.saved_tensors
+        plan, H, F, alpha, elu = ctx.meta
+        dout = _rows(dout)
+        dWh = torch.empty_like(Wh)
+        da = torch.zeros_like(a)
+        (w, ldw), (o, ldo), (g, ldg), (dw, ldd) = _m(Wh), _m(out), _m(dout), _m(dWh)
+        _check(_lib().dagnet_op_gat_attn_bwd(plan._h, _p(adj), _adj_ld(adj), w, ldw, _p(a), H, F, alpha, int(elu), o, ldo, g, ldg, dw, ldd, _p(da),
+                                             _stream(Wh.device)))
+        return dWh, da, None, None, None, None, None, None
+
+
+class BnFn(torch.autograd.Function):
+    """nn.BatchNorm1d in train mode (batch statistics over all rows, running statistics updated in place) + optional tanh."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, tanh_out):
+        M, N = x.shape
+        y = torch.empty_like(x)
+        stat = torch.empty(2 * N, dtype=torch.float32, device=x.device)
+        tmp = torch.empty(2 * N, dtype=torch.float32, device=x.device)
+        ws = _ws(x.device, _lib().dagnet_op_col_workspace(M, N))
+        (xp, ldx), (yp, ldy) = _m(x), _m(y)
+        _check(_lib().dagnet_op_bn_fwd(M, N, xp, ldx, _p(gamma), _p(beta), eps, momentum, int(tanh_out), yp, ldy, _p(stat),
+                                       _p(run_mean), _p(run_var), _p(tmp), _p(ws), _stream(x.device)))
+        ctx.save_for_backward(x, gamma, stat, y)
+        ctx.tanh_out = tanh_out
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stat, y = ctx.saved_tensors
+        M, N = x.shape
+        dy = _rows(dy)
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        sums = torch.empty(2 * N, dtype=torch.float32, device=x.device)
+        ws = _ws(x.device, _lib().dagnet_op_col_workspace(M, N))
+        (xp, ldx), (gp, ldg), (yp, ldy), (dp, ldd) = _m(x), _m(dy), _m(y), _m(dx)
+        _check(_lib().dagnet_op_bn_bwd(M, N, xp, ldx, _p(stat), _p(gamma), gp, ldg, yp, ldy, int(ctx.tanh_out), dp, ldd, _p(dgamma),
+                                       _p(dbeta), 0, _p(sums), _p(ws), _stream(x.device)))
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class AdjMatmulFn(torch.autograd.Function):
+    """adj @ x (+ bias) per scene (gcn_layers.py:20-26)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, adj, plan):
+        y = torch.empty_like(x)
+        (xp, ldx), (yp, ldy) = _m(x), _m(y)
+        _check(_lib().dagnet_op_adj_matmul(plan._h, x.shape[1], _p(adj), _adj_ld(adj), xp, ldx, _p(bias), 0, yp, ldy, _stream(x.device)))
+        ctx.save_for_backward(adj)
+        ctx.meta = (plan, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (adj,) = ctx.saved_tensors
+        plan, has_b = ctx.meta
+        dy = _rows(dy)
+        dx = torch.empty_like(dy)
+        (gp, ldg), (dp, ldd) = _m(dy), _m(dx)
+        _check(_lib().dagnet_op_adj_matmul(plan._h, dy.shape[1], _p(adj), _adj_ld(adj), gp, ldg, None, 1, dp, ldd, _stream(dy.device)))
+        db = None
+        if has_b and ctx.needs_input_grad[1]:
+            db = torch.empty(dy.shape[1], dtype=torch.float32, device=dy.device)
+            colsum(dy, db)
+        return dx, db, None, None
+
+
+def disposition(plan, pos: torch.Tensor, D: int) -> torch.Tensor:
+    """d_t [N, D]: every row carries the flattened xy of its scene's agents (models/dagnet/model.py:141-147); no gradient."""
+    out = torch.empty((pos.shape[0], D), dtype=torch.float32, device=pos.device)
+    _check(_lib().dagnet_op_disposition(plan._h, D, _p(pos.contiguous()), _p(out), D, _stream(pos.device)))
+    return out
+
+
+def bn_train(bn: torch.nn.BatchNorm1d, x: torch.Tensor, tanh_out: bool) -> torch.Tensor:
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    y = BnFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, tanh_out)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return y
+
+
+def gat_train(gat, x, adj, plan):
+    """GAT.forward in train mode (gat_model.py:18-22): P heads -> concat -> out head -> BatchNorm (batch statistics) -> tanh."""
+    P, F = gat.nheads, gat.nhid
+    Wcat = StackFn.apply(False, *[att.W for att in gat.attentions])
+    acat = StackFn.apply(True, *[att.a for att in gat.attentions])
+    Wh = MatmulFn.apply(x, Wcat)
+    x2 = GatAttnFn.apply(Wh, acat, adj, plan, P, F, float(gat.alpha), True)
+    Wh2 = MatmulFn.apply(x2, gat.out_att.W)
+    a2 = StackFn.apply(True, gat.out_att.a)
+    o = GatAttnFn.apply(Wh2, a2, adj, plan, 1, gat.nout, float(gat.alpha), False)
+    return bn_train(gat.bn1, o, True)
+
+
+def gcn_train(gcn, x, adj, plan):
+    """GCN.forward in train mode (gcn_model.py:14-19)."""
+    x = AdjMatmulFn.apply(MatmulFn.apply(x, gcn.gc1.weight), gcn.gc1.bias, adj, plan)
+    x = bn_train(gcn.bn1, x, False)
+    x = AdjMatmulFn.apply(MatmulFn.apply(x, gcn.gc2.weight), gcn.gc2.bias, adj, plan)
+    return bn_train(gcn.bn2, x, True)
+
+
+def gru_step(rnn: torch.nn.GRU, xs, cols, h_layers):
+    """One seq_len = 1 call of nn.GRU; xs/cols: the pieces of the layer-0 input.  -> list of new per-layer states."""
+    out = []
+    for l in range(rnn.num_layers):
+        Wih, Whh = getattr(rnn, f"weight_ih_l{l}"), getattr(rnn, f"weight_hh_l{l}")
+        bih, bhh = getattr(rnn, f"bias_ih_l{l}"), getattr(rnn, f"bias_hh_l{l}")
+        if l == 0:
+            gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, tuple(cols), None, 0, *xs)
+        else:
+            gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, (0,), None, 0, out[-1])
+        gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, h_layers[l])
+        out.append(GruCellFn.apply(gi, gh, h_layers[l]))
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# optimizer step: clip_grad_norm_ + Adam (train_bsk.py:289-290), two launches per parameter, no host sync
+# ---------------------------------------------------------------------------------------------
+class ClipAdam:
+    """torch.nn.utils.clip_grad_norm_(params, clip) followed by torch.optim.Adam(params, lr).step() (defaults:
+    betas (0.9, 0.999), eps 1e-8, no weight decay), as HIP kernels.  total_norm of the last step is kept on the device."""
+
+    def __init__(self, params, lr=1e-3, clip=10.0, betas=(0.9, 0.999), eps=1e-8):
+        self.params = [p for p in params]
+        self.lr, self.clip, self.betas, self.eps = lr, clip, betas, eps
+        self.step_count = 0
+        self.m = [torch.zeros_like(p) for p in self.params]
+        self.v = [torch.zeros_like(p) for p in self.params]
+        dev = self.params[0].device
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def zero_grad(self):
+        for p in self.params:
+            p.grad = None
+
+    def step(self):
+        lib = _lib()
+        live = [(p, m, v) for p, m, v in zip(self.params, self.m, self.v) if p.grad is not None]
+        if not live:
+            return
+        st = _stream(live[0][0].device)
+        self.sumsq.zero_()
+        for p, _, _ in live:
+            if not p.grad.is_contiguous():
+                p.grad = p.grad.contiguous()
+            _check(lib.dagnet_op_sumsq(p.grad.numel(), _p(p.grad), _p(self.sumsq), st))
+        self.step_count += 1
+        for p, m, v in live:
+            _check(lib.dagnet_op_adam(p.numel(), _p(p.data), _p(p.grad), _p(m), _p(v), _p(self.sumsq), float(self.clip or 0.0), self.lr,
+                                      self.betas[0], self.betas[1], self.eps, self.step_count, st))
+
+    def total_norm(self) -> torch.Tensor:
+        return self.sumsq.sqrt().float()

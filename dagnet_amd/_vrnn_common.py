@@ -49,9 +49,14 @@ class RolloutModule(nn.Module, HipBacked):
                                 seed or 0, return_goals)
 
     def _run_forward(self, scene_ptr, traj_rel, traj=None, goals=None, adj=None, adj_dense=True, eps=None, seed=None):
-        self._require_eval("forward")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) and self.training:
-            raise NotImplementedError("differentiable forward (training step) is not implemented in the HIP path yet")
+        if self.training and (self._has_batchnorm or
+                              (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()))):
+            # model.train(): batch-statistics BatchNorm and a differentiable result -- the layer-by-layer operators
+            # (training.py); the fused rollout kernels below are the eval-mode path
+            from .training import forward_train
+            kld, nll, ce, h = forward_train(self, scene_ptr, traj_rel, traj=traj, goals=goals,
+                                            adj=None if adj is None else adj.float(), eps=eps)
+            return (kld, nll, ce), h
         dev = traj_rel.device
         plan = self.hip_plan(dev, scene_ptr, 1)
         if seed is None and eps is None:

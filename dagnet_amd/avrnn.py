@@ -49,6 +49,8 @@ class AVRNN(RolloutModule):
         The reference signature has no seq_start_end; without it the scenes are read off adj's support."""
         sp, a, dense = resolve_adj(adj, x.shape[1], seq_start_end)
         losses, h = self._run_forward(sp, x, adj=a, adj_dense=dense, eps=eps, seed=seed)
+        if isinstance(losses, tuple):
+            return losses[0], losses[1], h
         return losses[0:1], losses[1:2], h
 
     def sample(self, samples_seq_len, h, x_abs_start, seq_start_end, eps=None, seed=None):

@@ -34,6 +34,8 @@ class VRNN(RolloutModule):
     def forward(self, x, eps=None, seed=None):
         """x [T,N,x_dim] relative coords -> (KLD[1], NLL[1], h[L,N,R]).  eps [T-1,N,Z] optional injected noise."""
         losses, h = self._run_forward(self._single_agent_ptr(x.shape[1]), x, eps=eps, seed=seed)
+        if isinstance(losses, tuple):
+            return losses[0], losses[1], h
         return losses[0:1], losses[1:2], h
 
     def sample(self, samples_seq_len, h, eps=None, seed=None):

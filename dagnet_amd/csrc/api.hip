@@ -1227,3 +1227,244 @@ extern "C" int dagnet_scene_min_sum(const dagnet_plan *p, int32_t K, const float
                                     static_cast<hipStream_t>(stream)));
     return DAGNET_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// training-step operators (row T): thin checked entry points over gemm_f32.hip / train_ops.hip
+// ---------------------------------------------------------------------------------------------
+extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
+                              int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
+                              const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st);
+extern "C" int64_t dn_gemm_tn_workspace(int M, int N, int K);
+extern "C" hipError_t dn_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int M, int N, int K,
+                                 float *part, int accumulate, hipStream_t st);
+extern "C" hipError_t dn_t_act_bwd(int64_t, int, const float *, int64_t, const float *, int64_t, float *, int64_t, int, float, hipStream_t);
+extern "C" hipError_t dn_t_copy2d(int64_t, int, const float *, int64_t, float *, int64_t, int, hipStream_t);
+extern "C" hipError_t dn_t_onehot_grad(int64_t, int, const float *, int64_t, const int32_t *, float *, int64_t, hipStream_t);
+extern "C" hipError_t dn_t_softmax_fwd(int64_t, int, const float *, int64_t, float *, int64_t, hipStream_t);
+extern "C" hipError_t dn_t_softmax_bwd(int64_t, int, const float *, int64_t, const float *, int64_t, float *, int64_t, hipStream_t);
+extern "C" hipError_t dn_t_gru_fwd(int64_t, int, const float *, const float *, const float *, float *, float *, hipStream_t);
+extern "C" hipError_t dn_t_gru_bwd(int64_t, int, const float *, const float *, const float *, const float *, float *, float *, float *,
+                                   hipStream_t);
+extern "C" hipError_t dn_t_vae_fwd(int64_t, int, const float *, const float *, const float *, const float *, const float *, float *, float *,
+                                   hipStream_t);
+extern "C" hipError_t dn_t_vae_bwd(int64_t, int, const float *, const float *, const float *, const float *, const float *, const float *,
+                                   const float *, float, float *, float *, float *, float *, hipStream_t);
+extern "C" hipError_t dn_t_nll_fwd(int64_t, int, const float *, const float *, const float *, float *, hipStream_t);
+extern "C" hipError_t dn_t_nll_bwd(int64_t, int, const float *, const float *, const float *, const float *, float, float *, float *, hipStream_t);
+extern "C" hipError_t dn_t_ce_fwd(int64_t, const float *, int64_t, const int32_t *, float *, hipStream_t);
+extern "C" hipError_t dn_t_ce_bwd(int64_t, int, const int32_t *, const float *, float *, int64_t, hipStream_t);
+extern "C" hipError_t dn_t_sum(int64_t, const float *, float, float *, int, hipStream_t);
+extern "C" int64_t dn_t_col_workspace(int64_t M, int N);
+extern "C" hipError_t dn_t_colsum(int64_t, int, const float *, int64_t, float *, int, float *, hipStream_t);
+extern "C" hipError_t dn_t_bn_fwd(int64_t, int, const float *, int64_t, const float *, const float *, float, float, int, float *, int64_t,
+                                  float *, float *, float *, float *, float *, hipStream_t);
+extern "C" hipError_t dn_t_bn_bwd(int64_t, int, const float *, int64_t, const float *, const float *, const float *, int64_t, const float *,
+                                  int64_t, int, float *, int64_t, float *, float *, int, float *, float *, hipStream_t);
+extern "C" int64_t dn_t_gat_lds_bytes(int n_max, int F, int backward);
+extern "C" hipError_t dn_t_gat_attn_fwd(const int32_t *, const int64_t *, int, int, int64_t, const float *, const float *, int64_t, const float *, int,
+                                        int, float, int, float *, int64_t, hipStream_t);
+extern "C" hipError_t dn_t_gat_attn_bwd(const int32_t *, const int64_t *, int, int, int64_t, const float *, const float *, int64_t, const float *, int,
+                                        int, float, int, const float *, int64_t, const float *, int64_t, float *, int64_t, float *,
+                                        hipStream_t);
+extern "C" hipError_t dn_t_adj_matmul(const int32_t *, const int64_t *, const int32_t *, int, int64_t, int, int64_t, const float *, const float *,
+                                      int64_t, const float *, int, float *, int64_t, hipStream_t);
+extern "C" hipError_t dn_t_disposition(const int32_t *, const int64_t *, const int32_t *, int, int64_t, int, const float *, float *, int64_t,
+                                       hipStream_t);
+extern "C" hipError_t dn_t_sumsq(int64_t, const float *, double *, hipStream_t);
+extern "C" hipError_t dn_t_adam(int64_t, float *, float *, float *, float *, const double *, float, float, float, float, float, float, float,
+                                hipStream_t);
+
+#define OP_ST static_cast<hipStream_t>(stream)
+#define OP_NEED(cond, msg)                                        \
+    do {                                                          \
+        if (!(cond)) return fail(DAGNET_ERR_INVALID, "%s", msg);  \
+    } while (0)
+
+extern "C" int dagnet_op_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int32_t transb, const float *bias, float *C,
+                              int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, float slope, int32_t accumulate,
+                              const float *gather, const int32_t *gidx, int64_t gs_g, int64_t gs_n, void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    if (M == 0 || N == 0) return DAGNET_OK;
+    OP_NEED(A && B && C, "null operand");
+    OP_NEED(lda >= K && ldc >= N && ldb >= (transb ? N : K), "row stride smaller than the row");
+    OP_NEED(!gather || gidx, "gather without indices");
+    HIP_TRY(dn_gemm(A, lda, B, ldb, transb, bias, C, ldc, M, N, K, act, slope, accumulate, gather, gidx, gs_g, gs_n, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int64_t dagnet_op_gemm_tn_workspace(int32_t M, int32_t N, int32_t K) { return dn_gemm_tn_workspace(M, N, K); }
+extern "C" int dagnet_op_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int32_t M, int32_t N,
+                                 int32_t K, float *workspace, int32_t accumulate, void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    if (N == 0 || K == 0) return DAGNET_OK;
+    OP_NEED(A && B && C && workspace, "null operand");
+    OP_NEED(lda >= N && ldb >= K && ldc >= K, "row stride smaller than the row");
+    HIP_TRY(dn_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, workspace, accumulate, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_act_bwd(int64_t M, int32_t N, const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp,
+                                 int32_t act, float slope, void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && (M * N == 0 || (dY && Y && dP)), "bad argument");
+    HIP_TRY(dn_t_act_bwd(M, N, dY, ldd, Y, ldy, dP, ldp, act, slope, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_copy2d(int64_t M, int32_t N, const float *src, int64_t lds, float *dst, int64_t ldd, int32_t accumulate,
+                                void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && (M * N == 0 || (src && dst)), "bad argument");
+    HIP_TRY(dn_t_copy2d(M, N, src, lds, dst, ldd, accumulate, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_onehot_grad(int64_t M, int32_t N, const float *dP, int64_t ldp, const int32_t *gidx, float *dW, int64_t ldw,
+                                     void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && (M * N == 0 || (dP && gidx && dW)), "bad argument");
+    HIP_TRY(dn_t_onehot_grad(M, N, dP, ldp, gidx, dW, ldw, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_softmax_fwd(int64_t M, int32_t N, const float *X, int64_t ldx, float *Y, int64_t ldy, void *stream) {
+    OP_NEED(M >= 0 && N >= 1 && (M == 0 || (X && Y)), "bad argument");
+    HIP_TRY(dn_t_softmax_fwd(M, N, X, ldx, Y, ldy, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_softmax_bwd(int64_t M, int32_t N, const float *Y, int64_t ldy, const float *dY, int64_t ldd, float *dX, int64_t ldx,
+                                     void *stream) {
+    OP_NEED(M >= 0 && N >= 1 && (M == 0 || (Y && dY && dX)), "bad argument");
+    HIP_TRY(dn_t_softmax_bwd(M, N, Y, ldy, dY, ldd, dX, ldx, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_gru_fwd(int64_t M, int32_t R, const float *gi, const float *gh, const float *h, float *hn, float *gates,
+                                 void *stream) {
+    OP_NEED(M >= 0 && R >= 1 && (M == 0 || (gi && gh && h && hn && gates)), "bad argument");
+    HIP_TRY(dn_t_gru_fwd(M, R, gi, gh, h, hn, gates, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_gru_bwd(int64_t M, int32_t R, const float *dhn, const float *gates, const float *gh, const float *h, float *dgi,
+                                 float *dgh, float *dh, void *stream) {
+    OP_NEED(M >= 0 && R >= 1 && (M == 0 || (dhn && gates && gh && h && dgi && dgh && dh)), "bad argument");
+    HIP_TRY(dn_t_gru_bwd(M, R, dhn, gates, gh, h, dgi, dgh, dh, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_vae_fwd(int64_t M, int32_t Z, const float *mu_e, const float *lv_e, const float *mu_p, const float *lv_p,
+                                 const float *eps, float *z, float *kld_row, void *stream) {
+    OP_NEED(M >= 0 && Z >= 1 && (M == 0 || (mu_e && lv_e && mu_p && lv_p && eps && z && kld_row)), "bad argument");
+    HIP_TRY(dn_t_vae_fwd(M, Z, mu_e, lv_e, mu_p, lv_p, eps, z, kld_row, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_vae_bwd(int64_t M, int32_t Z, const float *mu_e, const float *lv_e, const float *mu_p, const float *lv_p,
+                                 const float *eps, const float *dz, const float *g_kld, float scale, float *dmu_e, float *dlv_e,
+                                 float *dmu_p, float *dlv_p, void *stream) {
+    OP_NEED(M >= 0 && Z >= 1 && (M == 0 || (mu_e && lv_e && mu_p && lv_p && eps && dmu_e && dlv_e && dmu_p && dlv_p)), "bad argument");
+    HIP_TRY(dn_t_vae_bwd(M, Z, mu_e, lv_e, mu_p, lv_p, eps, dz, g_kld, scale, dmu_e, dlv_e, dmu_p, dlv_p, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_nll_fwd(int64_t M, int32_t X, const float *mu, const float *lv, const float *x, float *nll_row, void *stream) {
+    OP_NEED(M >= 0 && X >= 1 && (M == 0 || (mu && lv && x && nll_row)), "bad argument");
+    HIP_TRY(dn_t_nll_fwd(M, X, mu, lv, x, nll_row, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_nll_bwd(int64_t M, int32_t X, const float *mu, const float *lv, const float *x, const float *g, float scale,
+                                 float *dmu, float *dlv, void *stream) {
+    OP_NEED(M >= 0 && X >= 1 && (M == 0 || (mu && lv && x && g && dmu && dlv)), "bad argument");
+    HIP_TRY(dn_t_nll_bwd(M, X, mu, lv, x, g, scale, dmu, dlv, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_ce_fwd(int64_t M, const float *p, int64_t ldp, const int32_t *goal, float *ce_row, void *stream) {
+    OP_NEED(M >= 0 && (M == 0 || (p && goal && ce_row)), "bad argument");
+    HIP_TRY(dn_t_ce_fwd(M, p, ldp, goal, ce_row, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_ce_bwd(int64_t M, int32_t G, const int32_t *goal, const float *g, float *dp, int64_t ldp, void *stream) {
+    OP_NEED(M >= 0 && G >= 1 && (M == 0 || (goal && g && dp)), "bad argument");
+    HIP_TRY(dn_t_ce_bwd(M, G, goal, g, dp, ldp, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_sum(int64_t n, const float *x, float scale, float *out, int32_t accumulate, void *stream) {
+    OP_NEED(n >= 0 && out && (n == 0 || x), "bad argument");
+    HIP_TRY(dn_t_sum(n, x, scale, out, accumulate, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int64_t dagnet_op_col_workspace(int64_t M, int32_t N) { return dn_t_col_workspace(M, N); }
+extern "C" int dagnet_op_colsum(int64_t M, int32_t N, const float *X, int64_t ldx, float *out, int32_t accumulate, float *workspace,
+                                void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && (N == 0 || (out && workspace && (M == 0 || X))), "bad argument");
+    HIP_TRY(dn_t_colsum(M, N, X, ldx, out, accumulate, workspace, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_bn_fwd(int64_t M, int32_t N, const float *X, int64_t ldx, const float *gamma, const float *beta, float eps,
+                                float momentum, int32_t tanh_out, float *Y, int64_t ldy, float *stat, float *run_mean, float *run_var,
+                                float *tmp, float *workspace, void *stream) {
+    OP_NEED(M >= 1 && N >= 1 && X && gamma && beta && Y && stat && tmp && workspace, "bad argument");
+    OP_NEED((run_mean == nullptr) == (run_var == nullptr), "running_mean and running_var go together");
+    HIP_TRY(dn_t_bn_fwd(M, N, X, ldx, gamma, beta, eps, momentum, tanh_out, Y, ldy, stat, run_mean, run_var, tmp, workspace, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_bn_bwd(int64_t M, int32_t N, const float *X, int64_t ldx, const float *stat, const float *gamma, const float *dOut,
+                                int64_t ldd, const float *Out, int64_t ldo, int32_t tanh_out, float *dX, int64_t ldg, float *dgamma,
+                                float *dbeta, int32_t accumulate, float *sums, float *workspace, void *stream) {
+    OP_NEED(M >= 1 && N >= 1 && X && stat && gamma && dOut && dX && dgamma && dbeta && sums && workspace && (!tanh_out || Out),
+            "bad argument");
+    HIP_TRY(dn_t_bn_bwd(M, N, X, ldx, stat, gamma, dOut, ldd, Out, ldo, tanh_out, dX, ldg, dgamma, dbeta, accumulate, sums, workspace, OP_ST));
+    return DAGNET_OK;
+}
+static int op_plan(const dagnet_plan *p) {
+    if (!p) return fail(DAGNET_ERR_INVALID, "null plan");
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev != p->device)
+        return fail(DAGNET_ERR_INVALID, "plan belongs to device %d but device %d is current", p->device, dev);
+    return DAGNET_OK;
+}
+// adj_ld: 0 = compact block-diagonal adjacency (dagnet_adjacency layout), N = dense [N, N]
+static int op_adj(const dagnet_plan *p, int64_t adj_ld, const int64_t **off) {
+    if (adj_ld != 0 && adj_ld != p->N) return fail(DAGNET_ERR_INVALID, "adj_ld must be 0 (compact) or N");
+    *off = adj_ld ? p->d_off_dense : p->d_off_compact;
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_gat_attn_fwd(const dagnet_plan *p, const float *adj, int64_t adj_ld, const float *Wh, int64_t ldw, const float *a, int32_t H,
+                                      int32_t F, float alpha, int32_t elu, float *Out, int64_t ldo, void *stream) {
+    if (int rc = op_plan(p)) return rc;
+    OP_NEED(adj && Wh && a && Out && H >= 1 && F >= 1, "bad argument");
+    if (dn_t_gat_lds_bytes(p->AS, F, 0) > 64 * 1024)
+        return fail(DAGNET_ERR_CAPACITY, "graph attention with %d agents x %d features does not fit the LDS tile of the training kernels", p->AS, F);
+    const int64_t *off;
+    if (int rc = op_adj(p, adj_ld, &off)) return rc;
+    HIP_TRY(dn_t_gat_attn_fwd(p->d_scene_ptr, off, p->S, p->AS, adj_ld, adj, Wh, ldw, a, H, F, alpha, elu, Out, ldo, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_gat_attn_bwd(const dagnet_plan *p, const float *adj, int64_t adj_ld, const float *Wh, int64_t ldw, const float *a, int32_t H,
+                                      int32_t F, float alpha, int32_t elu, const float *Out, int64_t ldo, const float *dOut, int64_t ldd,
+                                      float *dWh, int64_t ldg, float *da, void *stream) {
+    if (int rc = op_plan(p)) return rc;
+    OP_NEED(adj && Wh && a && dOut && dWh && da && (!elu || Out) && H >= 1 && F >= 1, "bad argument");
+    if (dn_t_gat_lds_bytes(p->AS, F, 1) > 64 * 1024)
+        return fail(DAGNET_ERR_CAPACITY, "graph attention backward with %d agents x %d features does not fit the LDS tile of the training kernels", p->AS, F);
+    const int64_t *off;
+    if (int rc = op_adj(p, adj_ld, &off)) return rc;
+    HIP_TRY(dn_t_gat_attn_bwd(p->d_scene_ptr, off, p->S, p->AS, adj_ld, adj, Wh, ldw, a, H, F, alpha, elu, Out, ldo, dOut, ldd, dWh,
+                              ldg, da, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_adj_matmul(const dagnet_plan *p, int32_t F, const float *adj, int64_t adj_ld, const float *X, int64_t ldx, const float *bias,
+                                    int32_t transpose, float *Y, int64_t ldy, void *stream) {
+    if (int rc = op_plan(p)) return rc;
+    OP_NEED(adj && X && Y && F >= 1, "bad argument");
+    const int64_t *off;
+    if (int rc = op_adj(p, adj_ld, &off)) return rc;
+    HIP_TRY(dn_t_adj_matmul(p->d_scene_ptr, off, p->d_row_scene, p->S, p->N, F, adj_ld, adj, X, ldx, bias, transpose, Y, ldy, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_disposition(const dagnet_plan *p, int32_t D, const float *pos, float *out, int64_t ldo, void *stream) {
+    if (int rc = op_plan(p)) return rc;
+    OP_NEED(pos && out && D >= 2 * p->AS, "bad argument (D must hold 2 * the largest scene)");
+    HIP_TRY(dn_t_disposition(p->d_scene_ptr, p->d_off_compact, p->d_row_scene, p->S, p->N, D, pos, out, ldo, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_sumsq(int64_t n, const float *g, double *acc, void *stream) {
+    OP_NEED(n >= 0 && acc && (n == 0 || g), "bad argument");
+    HIP_TRY(dn_t_sumsq(n, g, acc, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_adam(int64_t n, float *p, float *g, float *m, float *v, const double *sumsq, float clip, float lr, float beta1,
+                              float beta2, float eps, int32_t step, void *stream) {
+    OP_NEED(n >= 0 && step >= 1 && (n == 0 || (p && g && m && v)) && (clip <= 0.f || sumsq), "bad argument");
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2 = (float)(1.0 - pow((double)beta2, (double)step));
+    HIP_TRY(dn_t_adam(n, p, g, m, v, sumsq, clip, lr, beta1, beta2, eps, bc1, bc2, OP_ST));
+    return DAGNET_OK;
+}

@@ -1,6 +1,7 @@
 // fp32 MFMA GEMMs for the layer-by-layer paths (wide goal head of SDD-shaped DAG-Net, training step).
 //
 //   NT:  C[M,N] = act(A[M,K] . W[N,K]^T + bias[N])            nn.Linear forward        (models/dagnet/model.py:60-113)
+//   NN:  C[M,N] = A[M,K] . B[K,N]                             x @ W of the graph layers, input gradients dY . W
 //   TN:  C[N,K] = sum_m A[m,N] . B[m,K]   (split over m)      weight gradients
 //
 // 256 threads = 4 waves per workgroup; every wave owns TM x TN accumulator tiles of v_mfma_f32_32x32x2_f32
@@ -29,8 +30,10 @@ struct NtArgs {
     float *C; int64_t ldc;            // [M, N]
     int M, N, K;
     float slope;                      // LeakyReLU slope
-    // optional one-hot input folded into the epilogue: C[m][n] += gather[gidx[m] * ldg + n]
-    const float *gather; const int32_t *gidx; int64_t ldg;
+    // optional one-hot input folded into the epilogue: C[m][n] += gather[gidx[m] * gs_g + n * gs_n]
+    const float *gather; const int32_t *gidx; int64_t gs_g, gs_n;
+    int act;                          // ACT_*
+    int accumulate;                   // C = act(C + A W^T + ...)
 };
 
 __device__ __forceinline__ float act_apply(int act, float v, float slope) {
@@ -41,7 +44,9 @@ __device__ __forceinline__ float act_apply(int act, float v, float slope) {
 }
 
 // Wave grid WM x WN (WM*WN == 4), per-wave TM x TN tiles of 32x32.  Tile of the workgroup: (WM*TM*32) x (WN*TN*32).
-template <int WM, int WN, int TM, int TN, int ACT>
+// VEC: float4 staging loads (needs 16-byte aligned operands, lda/ldw/K multiples of 4); else scalar loads.
+// TRANSB: the second operand is B[K, N] row-major (ldw = its row stride) instead of W[N, K].
+template <int WM, int WN, int TM, int TN, bool VEC, bool TRANSB>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;      // float4 loads per thread and chunk
@@ -61,23 +66,48 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
 
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;          // this thread's (row, k) inside a 32-row slab of a chunk
     f32x4 ga[LA], gb[LB];
+    // 4 consecutive elements of row r starting at column c of a [nr, nc] matrix, zero outside
+    auto ld4 = [&](const float *base, int64_t ld, int r, int nr, int c, int nc) {
+        f32x4 v = {0, 0, 0, 0};
+        if (r < nr) {
+            const float *q = base + (int64_t)r * ld + c;
+            if (VEC) {
+                if (c < nc) v = *reinterpret_cast<const f32x4 *>(q);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (c + i < nc) v[i] = q[i];
+            }
+        }
+        return v;
+    };
+    constexpr int BN4 = BN / 4;
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < LA; ++i) {
-            const int r = m0 + lrow + 32 * i, k = k0 + lc4;
-            ga[i] = (r < p.M && k < p.K) ? *reinterpret_cast<const f32x4 *>(p.A + (int64_t)r * p.lda + k) : f32x4{0, 0, 0, 0};
-        }
+        for (int i = 0; i < LA; ++i) ga[i] = ld4(p.A, p.lda, m0 + lrow + 32 * i, p.M, k0 + lc4, p.K);
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
-            const int r = n0 + lrow + 32 * i, k = k0 + lc4;
-            gb[i] = (r < p.N && k < p.K) ? *reinterpret_cast<const f32x4 *>(p.W + (int64_t)r * p.ldw + k) : f32x4{0, 0, 0, 0};
+            if (TRANSB) {      // element e of the [32 k][BN n] slab: 4 consecutive n of one k
+                const int e = tid + 256 * i, kr = e / BN4, c4 = (e % BN4) * 4;
+                gb[i] = ld4(p.W, p.ldw, k0 + kr, p.K, n0 + c4, p.N);
+            } else {
+                gb[i] = ld4(p.W, p.ldw, n0 + lrow + 32 * i, p.N, k0 + lc4, p.K);
+            }
         }
     };
     auto sstore = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < LA; ++i) *reinterpret_cast<f32x4 *>(sA + (buf * BM + lrow + 32 * i) * LDT + lc4) = ga[i];
 #pragma unroll
-        for (int i = 0; i < LB; ++i) *reinterpret_cast<f32x4 *>(sB + (buf * BN + lrow + 32 * i) * LDT + lc4) = gb[i];
+        for (int i = 0; i < LB; ++i) {
+            if (TRANSB) {
+                const int e = tid + 256 * i, kr = e / BN4, c4 = (e % BN4) * 4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sB[(buf * BN + c4 + c) * LDT + kr] = gb[i][c];
+            } else {
+                *reinterpret_cast<f32x4 *>(sB + (buf * BN + lrow + 32 * i) * LDT + lc4) = gb[i];
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -129,8 +159,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
                 const int row = rbase + (r & 3) + 8 * (r >> 2);
                 if (row < p.M && col < p.N) {
                     float v = acc[a][b][r] + bv;
-                    if (p.gather) v += p.gather[(int64_t)p.gidx[row] * p.ldg + col];
-                    p.C[(int64_t)row * p.ldc + col] = act_apply(ACT, v, p.slope);
+                    if (p.gather) v += p.gather[(int64_t)p.gidx[row] * p.gs_g + (int64_t)col * p.gs_n];
+                    float *dst = p.C + (int64_t)row * p.ldc + col;
+                    if (p.accumulate) v += *dst;
+                    *dst = act_apply(p.act, v, p.slope);
                 }
             }
         }
@@ -213,51 +245,58 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
     }
 }
 
-// out[i] (+)= sum_s part[s][i]   (deterministic second pass of the split reduction)
-__global__ void reduce_splits_kernel(const float *part, int64_t stride, int splits, int64_t n, float *out, int accumulate) {
+// out[r][c] (+)= sum_s part[s][r][c]   (deterministic second pass of the split reduction; out has row stride ldc)
+__global__ void reduce_splits_kernel(const float *part, int splits, int N, int K, float *out, int64_t ldc, int accumulate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)N * K;
     if (i >= n) return;
-    float s = accumulate ? out[i] : 0.f;
-    for (int k = 0; k < splits; ++k) s += part[k * stride + i];
-    out[i] = s;
+    float *dst = out + (i / K) * ldc + (i % K);
+    float s = accumulate ? *dst : 0.f;
+    for (int k = 0; k < splits; ++k) s += part[k * n + i];
+    *dst = s;
 }
 
 template <int WM, int WN, int TM, int TN>
-static hipError_t launch_nt_cfg(const NtArgs &a, int act, hipStream_t st) {
+static hipError_t launch_nt_cfg(const NtArgs &a, bool vec, bool transb, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
     const int64_t blocks = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
-    switch (act) {
-    case ACT_NONE: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, ACT_NONE>), dim3((unsigned)blocks), dim3(256), lds, st, a); break;
-    case ACT_LRELU: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, ACT_LRELU>), dim3((unsigned)blocks), dim3(256), lds, st, a); break;
-    case ACT_TANH: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, ACT_TANH>), dim3((unsigned)blocks), dim3(256), lds, st, a); break;
-    case ACT_RELU: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, ACT_RELU>), dim3((unsigned)blocks), dim3(256), lds, st, a); break;
-    default: return hipErrorInvalidValue;
-    }
+    const dim3 g((unsigned)blocks), t(256);
+    if (vec && !transb) hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, false>), g, t, lds, st, a);
+    else if (vec) hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, true>), g, t, lds, st, a);
+    else if (!transb) hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false, false>), g, t, lds, st, a);
+    else hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false, true>), g, t, lds, st, a);
     return hipGetLastError();
 }
 
 }  // namespace gemm
 
-// C = act(A W^T + bias).  Requires lda, ldw multiples of 4 floats and 16-byte aligned A, W (the float4 staging loads);
-// K is zero-filled per float4, so K must be a multiple of 4 as well.  ldc is free.
+// General entry: C = act([C +] A op(B) + bias + gather), op(B) = W[N,K]^T (transb = 0) or B[K,N] (transb = 1).
+// Aligned operands with strides and K (transb: N) multiples of 4 take float4 staging loads, anything else scalar loads.
+extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
+                              int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
+                              const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st) {
+    if (M <= 0 || N <= 0) return hipSuccess;
+    if (act < gemm::ACT_NONE || act > gemm::ACT_RELU) return hipErrorInvalidValue;
+    const bool vec = !((lda & 3) || (ldb & 3) || (K & 3) || (transb && (N & 3)) || (reinterpret_cast<uintptr_t>(A) & 15) ||
+                       (reinterpret_cast<uintptr_t>(B) & 15));
+    gemm::NtArgs a{A, lda, B, ldb, bias, C, ldc, M, N, K, slope, gather, gidx, gs_g, gs_n, act, accumulate};
+    if (N > 64) return gemm::launch_nt_cfg<2, 2, 2, 2>(a, vec, transb != 0, st);     // 128 x 128
+    if (N > 32) return gemm::launch_nt_cfg<4, 1, 2, 2>(a, vec, transb != 0, st);     // 256 x 64
+    return gemm::launch_nt_cfg<4, 1, 2, 1>(a, vec, transb != 0, st);                 // 256 x 32
+}
+
 extern "C" hipError_t dn_gemm_nt_gather(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *C,
                                         int64_t ldc, int M, int N, int K, int act, float slope, const float *gather,
                                         const int32_t *gidx, int64_t ldg, hipStream_t st) {
-    if (M <= 0 || N <= 0) return hipSuccess;
-    if ((lda & 3) || (ldw & 3) || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15) || (reinterpret_cast<uintptr_t>(W) & 15))
-        return hipErrorInvalidValue;
-    gemm::NtArgs a{A, lda, W, ldw, bias, C, ldc, M, N, K, slope, gather, gidx, ldg};
-    if (N > 64) return gemm::launch_nt_cfg<2, 2, 2, 2>(a, act, st);     // 128 x 128
-    if (N > 32) return gemm::launch_nt_cfg<4, 1, 2, 2>(a, act, st);     // 256 x 64
-    return gemm::launch_nt_cfg<4, 1, 2, 1>(a, act, st);                 // 256 x 32
+    return dn_gemm(A, lda, W, ldw, 0, bias, C, ldc, M, N, K, act, slope, 0, gather, gidx, ldg, 1, st);
 }
 
 extern "C" hipError_t dn_gemm_nt(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *C, int64_t ldc,
                                  int M, int N, int K, int act, float slope, hipStream_t st) {
-    return dn_gemm_nt_gather(A, lda, W, ldw, bias, C, ldc, M, N, K, act, slope, nullptr, nullptr, 0, st);
+    return dn_gemm(A, lda, W, ldw, 0, bias, C, ldc, M, N, K, act, slope, 0, nullptr, nullptr, 0, 0, st);
 }
 
 // C[N,K] (+)= A[M,N]^T B[M,K], deterministic two-pass split over M.  `part` is a workspace of
@@ -279,14 +318,7 @@ extern "C" hipError_t dn_gemm_tn(const float *A, int64_t lda, const float *B, in
     hipLaunchKernelGGL(gemm::gemm_tn_kernel, dim3(blocks, splits), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    // the second pass writes rows of C with stride ldc: handle ldc == K in one launch, else row by row
-    if (ldc == K) {
-        const int64_t n = (int64_t)N * K;
-        hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, n, splits, n, C, accumulate);
-    } else {
-        for (int r = 0; r < N; ++r)
-            hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((K + 255) / 256), dim3(256), 0, st, part + (int64_t)r * K, (int64_t)N * K,
-                               splits, (int64_t)K, C + (int64_t)r * ldc, accumulate);
-    }
+    const int64_t n = (int64_t)N * K;
+    hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, splits, N, K, C, ldc, accumulate);
     return hipGetLastError();
 }

@@ -1,0 +1,713 @@
+// Row-wise, per-scene and optimizer kernels of the training step (row T: models/dagnet/train_bsk.py:259-291 and the
+// avrnn / baseline analogues).  The differentiable forward() runs layer by layer over all N rows of the batch:
+// dense layers are the fp32 MFMA GEMMs of gemm_f32.hip, everything between them lives here, each op with its
+// hand-written backward.  Host side: dagnet_amd/_ops.py (torch.autograd.Function wrappers that only allocate).
+//
+// All matrices are row-major fp32 with an explicit row stride (ld*).  Scene structure comes from a dagnet_plan
+// (scene_ptr, row -> scene, offsets of the compact block-diagonal adjacency).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace tops {
+
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_RELU = 3 };
+
+__device__ __forceinline__ int64_t gid() { return (int64_t)blockIdx.x * blockDim.x + threadIdx.x; }
+
+// ---------------------------------------------------------------------------------------------
+// element-wise
+// ---------------------------------------------------------------------------------------------
+// dPre = dY * act'(pre), expressed through the saved output Y (slope > 0 keeps the sign)
+__global__ void act_bwd_kernel(int64_t M, int N, const float *__restrict__ dY, int64_t ldd, const float *__restrict__ Y, int64_t ldy,
+                               float *__restrict__ dP, int64_t ldp, int act, float slope) {
+    const int64_t i = gid();
+    if (i >= M * N) return;
+    const int64_t r = i / N;
+    const int c = (int)(i - r * N);
+    const float y = Y[r * ldy + c], g = dY[r * ldd + c];
+    float d = 1.f;
+    if (act == ACT_LRELU) d = y > 0.f ? 1.f : slope;
+    else if (act == ACT_RELU) d = y > 0.f ? 1.f : 0.f;
+    else if (act == ACT_TANH) d = 1.f - y * y;
+    dP[r * ldp + c] = g * d;
+}
+
+__global__ void copy2d_kernel(int64_t M, int N, const float *__restrict__ src, int64_t lds, float *__restrict__ dst, int64_t ldd,
+                              int accumulate) {
+    const int64_t i = gid();
+    if (i >= M * N) return;
+    const int64_t r = i / N;
+    const int c = (int)(i - r * N);
+    const float v = src[r * lds + c];
+    float *d = dst + r * ldd + c;
+    *d = accumulate ? *d + v : v;
+}
+
+// rows of one-hot inputs: dW[n][gidx[m]] += dP[m][n]   (dW already offset to the one-hot column block)
+__global__ void onehot_grad_kernel(int64_t M, int N, const float *__restrict__ dP, int64_t ldp, const int32_t *__restrict__ gidx,
+                                   float *__restrict__ dW, int64_t ldw) {
+    const int64_t i = gid();
+    if (i >= M * N) return;
+    const int64_t m = i / N;
+    const int n = (int)(i - m * N);
+    atomicAdd(dW + (int64_t)n * ldw + gidx[m], dP[m * ldp + n]);
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// one wave per row
+__global__ void softmax_fwd_kernel(int64_t M, int N, const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy) {
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float *x = X + r * ldx;
+    float mx = -INFINITY;
+    for (int c = lane; c < N; c += 64) mx = fmaxf(mx, x[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < N; c += 64) s += expf(x[c] - mx);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int c = lane; c < N; c += 64) Y[r * ldy + c] = expf(x[c] - mx) * inv;
+}
+
+// dX = Y * (dY - sum(dY * Y))
+__global__ void softmax_bwd_kernel(int64_t M, int N, const float *__restrict__ Y, int64_t ldy, const float *__restrict__ dY, int64_t ldd,
+                                   float *__restrict__ dX, int64_t ldx) {
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= M) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int c = lane; c < N; c += 64) s += dY[r * ldd + c] * Y[r * ldy + c];
+    s = wave_sum(s);
+    for (int c = lane; c < N; c += 64) dX[r * ldx + c] = Y[r * ldy + c] * (dY[r * ldd + c] - s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GRU cell (nn.GRU gate order r, z, n):  gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh  come from the GEMMs
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sigm(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+__global__ void gru_fwd_kernel(int64_t M, int R, const float *__restrict__ gi, const float *__restrict__ gh, const float *__restrict__ h,
+                               float *__restrict__ hn, float *__restrict__ gates) {      // gates [M][3R]: r, z, n
+    const int64_t i = gid();
+    if (i >= M * R) return;
+    const int64_t m = i / R;
+    const int f = (int)(i - m * R);
+    const float *a = gi + m * 3 * R, *b = gh + m * 3 * R;
+    const float r = sigm(a[f] + b[f]), z = sigm(a[R + f] + b[R + f]);
+    const float n = tanhf(a[2 * R + f] + r * b[2 * R + f]);
+    hn[i] = (1.0f - z) * n + z * h[i];
+    float *g = gates + m * 3 * R;
+    g[f] = r; g[R + f] = z; g[2 * R + f] = n;
+}
+
+// -> dgi, dgh [M][3R], dh [M][R] (the direct z * dhn path only; the W_hh path is a GEMM on dgh)
+__global__ void gru_bwd_kernel(int64_t M, int R, const float *__restrict__ dhn, const float *__restrict__ gates,
+                               const float *__restrict__ gh, const float *__restrict__ h, float *__restrict__ dgi,
+                               float *__restrict__ dgh, float *__restrict__ dh) {
+    const int64_t i = gid();
+    if (i >= M * R) return;
+    const int64_t m = i / R;
+    const int f = (int)(i - m * R);
+    const float *g = gates + m * 3 * R;
+    const float r = g[f], z = g[R + f], n = g[2 * R + f];
+    const float ghn = gh[m * 3 * R + 2 * R + f];
+    const float d = dhn[i];
+    const float dn = d * (1.0f - z), dz = d * (h[i] - n);
+    const float dpn = dn * (1.0f - n * n);
+    const float dpr = dpn * ghn * r * (1.0f - r);
+    const float dpz = dz * z * (1.0f - z);
+    float *a = dgi + m * 3 * R, *b = dgh + m * 3 * R;
+    a[f] = dpr; a[R + f] = dpz; a[2 * R + f] = dpn;
+    b[f] = dpr; b[R + f] = dpz; b[2 * R + f] = dpn * r;
+    dh[i] = d * z;
+}
+
+// ---------------------------------------------------------------------------------------------
+// latent sample + losses (models/dagnet/model.py:118-135); per-row partial sums, reduced by sum_kernel
+// ---------------------------------------------------------------------------------------------
+// z = eps * exp(0.5 lv_e) + mu_e ;  kld_row = 0.5 * sum_z (lv_p - lv_e + (exp(lv_e) + (mu_e - mu_p)^2) / exp(lv_p) - 1)
+__global__ void vae_fwd_kernel(int64_t M, int Z, const float *__restrict__ mu_e, const float *__restrict__ lv_e,
+                               const float *__restrict__ mu_p, const float *__restrict__ lv_p, const float *__restrict__ eps,
+                               float *__restrict__ z, float *__restrict__ kld_row) {
+    const int64_t m = gid();
+    if (m >= M) return;
+    float acc = 0.f;
+    for (int c = 0; c < Z; ++c) {
+        const int64_t i = m * Z + c;
+        const float me = mu_e[i], le = lv_e[i], mp = mu_p[i], lp = lv_p[i];
+        z[i] = eps[i] * expf(0.5f * le) + me;
+        const float d = me - mp;
+        acc += (lp - le) + (expf(le) + d * d) / expf(lp) - 1.0f;
+    }
+    kld_row[m] = 0.5f * acc;
+}
+
+__global__ void vae_bwd_kernel(int64_t M, int Z, const float *__restrict__ mu_e, const float *__restrict__ lv_e,
+                               const float *__restrict__ mu_p, const float *__restrict__ lv_p, const float *__restrict__ eps,
+                               const float *__restrict__ dz, const float *__restrict__ g_kld, float scale, float *__restrict__ dmu_e,
+                               float *__restrict__ dlv_e, float *__restrict__ dmu_p, float *__restrict__ dlv_p) {
+    const int64_t i = gid();
+    if (i >= M * Z) return;
+    const float g = g_kld ? g_kld[0] * scale : 0.f;
+    const float me = mu_e[i], le = lv_e[i], mp = mu_p[i], lp = lv_p[i];
+    const float d = me - mp, ip = 1.0f / expf(lp), ee = expf(le);
+    const float dzz = dz ? dz[i] : 0.f;
+    dmu_e[i] = dzz + g * d * ip;
+    dlv_e[i] = dzz * eps[i] * 0.5f * expf(0.5f * le) + g * 0.5f * (ee * ip - 1.0f);
+    dmu_p[i] = -g * d * ip;
+    dlv_p[i] = g * 0.5f * (1.0f - (ee + d * d) * ip);
+}
+
+// nll_row = 0.5 * sum_c ((x - mu)^2 / exp(lv) + lv + log(2 pi))
+__global__ void nll_fwd_kernel(int64_t M, int X, const float *__restrict__ mu, const float *__restrict__ lv, const float *__restrict__ x,
+                               float *__restrict__ nll_row) {
+    const int64_t m = gid();
+    if (m >= M) return;
+    float acc = 0.f;
+    for (int c = 0; c < X; ++c) {
+        const int64_t i = m * X + c;
+        const float d = x[i] - mu[i];
+        acc += d * d / expf(lv[i]) + lv[i] + 1.8378770664093453f;
+    }
+    nll_row[m] = 0.5f * acc;
+}
+
+__global__ void nll_bwd_kernel(int64_t M, int X, const float *__restrict__ mu, const float *__restrict__ lv, const float *__restrict__ x,
+                               const float *__restrict__ g_nll, float scale, float *__restrict__ dmu, float *__restrict__ dlv) {
+    const int64_t i = gid();
+    if (i >= M * X) return;
+    const float g = g_nll[0] * scale;
+    const float d = x[i] - mu[i], iv = 1.0f / expf(lv[i]);
+    dmu[i] = -g * d * iv;
+    dlv[i] = g * 0.5f * (1.0f - d * d * iv);
+}
+
+// ce_row = -p[m][goal[m]]   (the reference sums g_t * probabilities, not log-probabilities: model.py:162)
+__global__ void ce_fwd_kernel(int64_t M, const float *__restrict__ p, int64_t ldp, const int32_t *__restrict__ goal,
+                              float *__restrict__ ce_row) {
+    const int64_t m = gid();
+    if (m >= M) return;
+    ce_row[m] = -p[m * ldp + goal[m]];
+}
+
+__global__ void ce_bwd_kernel(int64_t M, int G, const int32_t *__restrict__ goal, const float *__restrict__ g_ce, float *__restrict__ dp,
+                              int64_t ldp) {
+    const int64_t i = gid();
+    if (i >= M * G) return;
+    const int64_t m = i / G;
+    const int c = (int)(i - m * G);
+    dp[m * ldp + c] = c == goal[m] ? -g_ce[0] : 0.f;
+}
+
+// out[0] (+)= scale * sum of x[0..n) in fp64, one workgroup, fixed order
+__global__ __launch_bounds__(1024) void sum_kernel(int64_t n, const float *__restrict__ x, float scale, float *__restrict__ out, int accumulate) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)x[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)((accumulate ? (double)out[0] : 0.0) + red[0] * (double)scale);
+}
+
+// ---------------------------------------------------------------------------------------------
+// column reductions over the rows (bias gradients, BatchNorm statistics): two deterministic stages
+// ---------------------------------------------------------------------------------------------
+// stage 1: grid (ceil(N/64), splits), block 256 = 64 columns x 4 row lanes; part[split][q][N]
+// MODE 0: q0 = sum x                                   (bias gradient, BN mean)
+// MODE 1: q0 = sum (x - mu)^2                          (BN variance, second pass)
+// MODE 2: q0 = sum g, q1 = sum g * xhat, g = dOut * (1 - out^2) [tanh] or dOut;  xhat = (x - mu) * invstd
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(int64_t M, int N, int rows_per_split, const float *__restrict__ X, int64_t ldx,
+                                                         const float *__restrict__ stat, const float *__restrict__ dOut, int64_t ldd,
+                                                         const float *__restrict__ Out, int64_t ldo, int tanh_out,
+                                                         float *__restrict__ part) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int64_t m0 = (int64_t)blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
+    float q0 = 0.f, q1 = 0.f;
+    if (c < N) {
+        const float mu = MODE >= 1 ? stat[c] : 0.f, is = MODE == 2 ? stat[N + c] : 0.f;
+        for (int64_t m = m0 + rl; m < m1; m += 4) {
+            if (MODE == 0) q0 += X[m * ldx + c];
+            else if (MODE == 1) { const float d = X[m * ldx + c] - mu; q0 += d * d; }
+            else {
+                float g = dOut[m * ldd + c];
+                if (tanh_out) { const float o = Out[m * ldo + c]; g *= 1.0f - o * o; }
+                q0 += g;
+                q1 += g * (X[m * ldx + c] - mu) * is;
+            }
+        }
+    }
+    red[0][rl][threadIdx.x & 63] = q0;
+    red[1][rl][threadIdx.x & 63] = q1;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        const int l = threadIdx.x;
+        part[((int64_t)blockIdx.y * 2 + 0) * N + c] = (red[0][0][l] + red[0][1][l]) + (red[0][2][l] + red[0][3][l]);
+        part[((int64_t)blockIdx.y * 2 + 1) * N + c] = (red[1][0][l] + red[1][1][l]) + (red[1][2][l] + red[1][3][l]);
+    }
+}
+
+// stage 2: out_q[c] (+)= scale * sum_split part[split][q][c]
+__global__ void col_finish_kernel(int N, int splits, const float *__restrict__ part, float scale, float *__restrict__ out0,
+                                  float *__restrict__ out1, int accumulate) {
+    const int c = (int)gid();
+    if (c >= N) return;
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < splits; ++k) {
+        s0 += (double)part[((int64_t)k * 2 + 0) * N + c];
+        s1 += (double)part[((int64_t)k * 2 + 1) * N + c];
+    }
+    if (out0) out0[c] = (accumulate ? out0[c] : 0.f) + (float)(s0 * scale);
+    if (out1) out1[c] = (accumulate ? out1[c] : 0.f) + (float)(s1 * scale);
+}
+
+// BatchNorm1d in train mode (+ optional tanh): stat = [mean | invstd]; running statistics follow nn.BatchNorm1d
+// (momentum 0.1, unbiased variance).  var_sum = sum (x - mean)^2.
+__global__ void bn_stat_kernel(int N, int64_t M, const float *__restrict__ mean, const float *__restrict__ var_sum, float eps,
+                               float momentum, float *__restrict__ stat, float *__restrict__ run_mean, float *__restrict__ run_var) {
+    const int c = (int)gid();
+    if (c >= N) return;
+    const float var = var_sum[c] / (float)M;
+    stat[c] = mean[c];
+    stat[N + c] = 1.0f / sqrtf(var + eps);
+    if (run_mean) {
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean[c];
+        const float unb = M > 1 ? var_sum[c] / (float)(M - 1) : var;
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * unb;
+    }
+}
+
+__global__ void bn_apply_kernel(int64_t M, int N, const float *__restrict__ X, int64_t ldx, const float *__restrict__ stat,
+                                const float *__restrict__ gamma, const float *__restrict__ beta, int tanh_out, float *__restrict__ Y,
+                                int64_t ldy) {
+    const int64_t i = gid();
+    if (i >= M * N) return;
+    const int64_t m = i / N;
+    const int c = (int)(i - m * N);
+    const float v = (X[m * ldx + c] - stat[c]) * stat[N + c] * gamma[c] + beta[c];
+    Y[m * ldy + c] = tanh_out ? tanhf(v) : v;
+}
+
+// dX = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat));  sums = [sum g | sum g xhat]
+__global__ void bn_bwd_kernel(int64_t M, int N, const float *__restrict__ X, int64_t ldx, const float *__restrict__ stat,
+                              const float *__restrict__ gamma, const float *__restrict__ dOut, int64_t ldd,
+                              const float *__restrict__ Out, int64_t ldo, int tanh_out, const float *__restrict__ sums,
+                              float *__restrict__ dX, int64_t ldg) {
+    const int64_t i = gid();
+    if (i >= M * N) return;
+    const int64_t m = i / N;
+    const int c = (int)(i - m * N);
+    float g = dOut[m * ldd + c];
+    if (tanh_out) { const float o = Out[m * ldo + c]; g *= 1.0f - o * o; }
+    const float xhat = (X[m * ldx + c] - stat[c]) * stat[N + c];
+    const float inv_m = 1.0f / (float)M;
+    dX[m * ldg + c] = gamma[c] * stat[N + c] * (g - sums[c] * inv_m - xhat * sums[N + c] * inv_m);
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-scene graph kernels on the compact block-diagonal adjacency
+// ---------------------------------------------------------------------------------------------
+struct Scenes {
+    const int32_t *scene_ptr;
+    const int64_t *off;        // start of every scene's block: compact offsets, or b * N + b for a dense [N, N] matrix
+    int S;
+    int64_t ld;                // 0: compact blocks (row stride = the scene's agent count); else the dense row stride N
+};
+
+// GAT attention of one layer (gat_layers.py:25-40) for H heads of width F stacked along the columns of Wh:
+//   s1_i = Wh_i . a[:F], s2_j = Wh_j . a[F:], e_ij = leakyrelu(s1_i + s2_j) where adj_ij > 0, att = softmax_j, out = att Wh (elu)
+// grid (S, H); dynamic LDS: Wh [n][F] | s1 [n] | s2 [n] | att [n][n]
+__global__ __launch_bounds__(128) void gat_attn_fwd_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
+                                                          int64_t ldw, const float *__restrict__ a, int F, float alpha, int elu,
+                                                          float *__restrict__ Out, int64_t ldo) {
+    extern __shared__ float sm[];
+    const int s = blockIdx.x, hd = blockIdx.y;
+    const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b;
+    float *wh = sm, *s1 = wh + n * F, *s2 = s1 + n, *att = s2 + n;
+    const float *ah = a + (int64_t)hd * 2 * F;
+    const float *ablk = adj + sc.off[s];
+    const int64_t rld = sc.ld ? sc.ld : n;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * F; e += 128) wh[e] = Wh[(int64_t)(b + e / F) * ldw + hd * F + e % F];
+    __syncthreads();
+    for (int i = tid; i < n; i += 128) {
+        float u = 0.f, v = 0.f;
+        for (int f = 0; f < F; ++f) { u += wh[i * F + f] * ah[f]; v += wh[i * F + f] * ah[F + f]; }
+        s1[i] = u; s2[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 128) {
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j)
+            if (ablk[i * rld + j] > 0.f) { const float e = s1[i] + s2[j]; mx = fmaxf(mx, fmaxf(e, e * alpha)); }
+        float sum = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float w = 0.f;
+            if (ablk[i * rld + j] > 0.f) { const float e = s1[i] + s2[j]; w = expf(fmaxf(e, e * alpha) - mx); }
+            att[i * n + j] = w;
+            sum += w;
+        }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < n; ++j) att[i * n + j] *= inv;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * F; e += 128) {
+        const int i = e / F, f = e % F;
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) acc += att[i * n + j] * wh[j * F + f];
+        if (elu) acc = acc > 0.f ? acc : expm1f(acc);
+        Out[(int64_t)(b + i) * ldo + hd * F + f] = acc;
+    }
+}
+
+// backward of the above.  dynamic LDS: Wh [n][F] | dO [n][F] | dWh [n][F] | s1 | s2 | ds1 | ds2 [n] each | att [n][n] | dpre [n][n]
+// da (H x 2F) is accumulated with atomics over the scenes.
+__global__ __launch_bounds__(128) void gat_attn_bwd_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
+                                                          int64_t ldw, const float *__restrict__ a, int F, float alpha, int elu,
+                                                          const float *__restrict__ Out, int64_t ldo, const float *__restrict__ dOut,
+                                                          int64_t ldd, float *__restrict__ dWh, int64_t ldg, float *__restrict__ da) {
+    extern __shared__ float sm[];
+    const int s = blockIdx.x, hd = blockIdx.y;
+    const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b;
+    float *wh = sm, *dO = wh + n * F, *dw = dO + n * F, *s1 = dw + n * F, *s2 = s1 + n, *ds1 = s2 + n, *ds2 = ds1 + n;
+    float *att = ds2 + n, *dpre = att + n * n;
+    const float *ah = a + (int64_t)hd * 2 * F;
+    const float *ablk = adj + sc.off[s];
+    const int64_t rld = sc.ld ? sc.ld : n;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * F; e += 128) {
+        const int64_t row = b + e / F;
+        const int col = hd * F + e % F;
+        wh[e] = Wh[row * ldw + col];
+        float g = dOut[row * ldd + col];
+        if (elu) { const float o = Out[row * ldo + col]; g *= o > 0.f ? 1.f : o + 1.f; }
+        dO[e] = g;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 128) {
+        float u = 0.f, v = 0.f;
+        for (int f = 0; f < F; ++f) { u += wh[i * F + f] * ah[f]; v += wh[i * F + f] * ah[F + f]; }
+        s1[i] = u; s2[i] = v;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 128) {
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j)
+            if (ablk[i * rld + j] > 0.f) { const float e = s1[i] + s2[j]; mx = fmaxf(mx, fmaxf(e, e * alpha)); }
+        float sum = 0.f;
+        for (int j = 0; j < n; ++j) {
+            float w = 0.f;
+            if (ablk[i * rld + j] > 0.f) { const float e = s1[i] + s2[j]; w = expf(fmaxf(e, e * alpha) - mx); }
+            att[i * n + j] = w;
+            sum += w;
+        }
+        const float inv = 1.0f / sum;
+        // d att_ij = dO_i . Wh_j ;  d e_ij = att_ij (d att_ij - sum_k att_ik d att_ik) ;  through the leaky relu
+        float dot = 0.f;
+        for (int j = 0; j < n; ++j) {
+            att[i * n + j] *= inv;
+            float d = 0.f;
+            for (int f = 0; f < F; ++f) d += dO[i * F + f] * wh[j * F + f];
+            dpre[i * n + j] = d;
+            dot += att[i * n + j] * d;
+        }
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float e = s1[i] + s2[j];
+            const float de = att[i * n + j] * (dpre[i * n + j] - dot) * (e > 0.f ? 1.f : alpha);
+            dpre[i * n + j] = de;
+            acc += de;
+        }
+        ds1[i] = acc;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += 128) {
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += dpre[i * n + j];
+        ds2[j] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * F; e += 128) {
+        const int j = e / F, f = e % F;
+        float acc = ds1[j] * ah[f] + ds2[j] * ah[F + f];
+        for (int i = 0; i < n; ++i) acc += att[i * n + j] * dO[i * F + f];
+        dWh[(int64_t)(b + j) * ldg + hd * F + f] = acc;
+    }
+    for (int f = tid; f < 2 * F; f += 128) {
+        const float *ds = f < F ? ds1 : ds2;
+        const int ff = f < F ? f : f - F;
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += ds[i] * wh[i * F + ff];
+        atomicAdd(da + (int64_t)hd * 2 * F + f, acc);
+    }
+}
+
+// GCN aggregation (gcn_layers.py:20-26): Y_i = sum_j adj_ij X_j (+ bias);  transpose: Y_j = sum_i adj_ij X_i (backward)
+__global__ void adj_matmul_kernel(Scenes sc, const int32_t *__restrict__ row_scene, int64_t Nrows, int F, const float *__restrict__ adj,
+                                  const float *__restrict__ X, int64_t ldx, const float *__restrict__ bias, int transpose,
+                                  float *__restrict__ Y, int64_t ldy) {
+    const int64_t idx = gid();
+    if (idx >= Nrows * F) return;
+    const int64_t r = idx / F;
+    const int f = (int)(idx - r * F);
+    const int s = row_scene[r];
+    const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, i = (int)(r - b);
+    const float *ablk = adj + sc.off[s];
+    const int64_t rld = sc.ld ? sc.ld : n;
+    float acc = bias ? bias[f] : 0.f;
+    for (int j = 0; j < n; ++j) acc += (transpose ? ablk[j * rld + i] : ablk[i * rld + j]) * X[(int64_t)(b + j) * ldx + f];
+    Y[r * ldy + f] = acc;
+}
+
+// disposition d_t (models/dagnet/model.py:141-147): row r gets the flattened xy of its scene's agents, zero padded to D
+__global__ void disposition_kernel(Scenes sc, const int32_t *__restrict__ row_scene, int64_t Nrows, int D, const float *__restrict__ pos,
+                                   float *__restrict__ out, int64_t ldo) {
+    const int64_t idx = gid();
+    if (idx >= Nrows * D) return;
+    const int64_t r = idx / D;
+    const int c = (int)(idx - r * D);
+    const int s = row_scene[r];
+    const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b;
+    const int j = c >> 1;
+    out[r * ldo + c] = j < n ? pos[(int64_t)(b + j) * 2 + (c & 1)] : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer: clip_grad_norm_ + Adam (torch.optim.Adam defaults), no host synchronisation
+// ---------------------------------------------------------------------------------------------
+// acc[0] += sum g^2 (fp64); one workgroup per call keeps the order fixed
+__global__ __launch_bounds__(1024) void sumsq_kernel(int64_t n, const float *__restrict__ g, double *__restrict__ acc) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) s += (double)g[i] * (double)g[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acc[0] += red[0];
+}
+
+// coef = min(1, clip / (sqrt(sumsq) + 1e-6)) (torch.nn.utils.clip_grad_norm_); the gradient is scaled in place
+__global__ void adam_kernel(int64_t n, float *__restrict__ p, float *__restrict__ g, float *__restrict__ m, float *__restrict__ v,
+                            const double *__restrict__ sumsq, float clip, float lr, float b1, float b2, float eps, float bc1, float bc2) {
+    const int64_t i = gid();
+    if (i >= n) return;
+    float coef = 1.f;
+    if (clip > 0.f) coef = fminf(1.0f, clip / ((float)sqrt(sumsq[0]) + 1e-6f));
+    const float gi = g[i] * coef;
+    g[i] = gi;
+    const float mi = b1 * m[i] + (1.0f - b1) * gi;
+    const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    p[i] -= (lr / bc1) * mi / denom;
+}
+
+}   // namespace tops
+
+// ---------------------------------------------------------------------------------------------
+// launchers (called from api.hip, which validates arguments and owns the C ABI)
+// ---------------------------------------------------------------------------------------------
+#define T_GRID(total) dim3((unsigned)(((total) + 255) / 256)), dim3(256)
+
+extern "C" hipError_t dn_t_act_bwd(int64_t M, int N, const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp,
+                                   int act, float slope, hipStream_t st) {
+    if (M * N == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::act_bwd_kernel, T_GRID(M * N), 0, st, M, N, dY, ldd, Y, ldy, dP, ldp, act, slope);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_copy2d(int64_t M, int N, const float *src, int64_t lds, float *dst, int64_t ldd, int accumulate, hipStream_t st) {
+    if (M * N == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::copy2d_kernel, T_GRID(M * N), 0, st, M, N, src, lds, dst, ldd, accumulate);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_onehot_grad(int64_t M, int N, const float *dP, int64_t ldp, const int32_t *gidx, float *dW, int64_t ldw,
+                                       hipStream_t st) {
+    if (M * N == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::onehot_grad_kernel, T_GRID(M * N), 0, st, M, N, dP, ldp, gidx, dW, ldw);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_softmax_fwd(int64_t M, int N, const float *X, int64_t ldx, float *Y, int64_t ldy, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::softmax_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, N, X, ldx, Y, ldy);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_softmax_bwd(int64_t M, int N, const float *Y, int64_t ldy, const float *dY, int64_t ldd, float *dX, int64_t ldx,
+                                       hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::softmax_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, N, Y, ldy, dY, ldd, dX, ldx);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_gru_fwd(int64_t M, int R, const float *gi, const float *gh, const float *h, float *hn, float *gates,
+                                   hipStream_t st) {
+    if (M * R == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::gru_fwd_kernel, T_GRID(M * R), 0, st, M, R, gi, gh, h, hn, gates);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_gru_bwd(int64_t M, int R, const float *dhn, const float *gates, const float *gh, const float *h, float *dgi,
+                                   float *dgh, float *dh, hipStream_t st) {
+    if (M * R == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::gru_bwd_kernel, T_GRID(M * R), 0, st, M, R, dhn, gates, gh, h, dgi, dgh, dh);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_vae_fwd(int64_t M, int Z, const float *mu_e, const float *lv_e, const float *mu_p, const float *lv_p,
+                                   const float *eps, float *z, float *kld_row, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::vae_fwd_kernel, T_GRID(M), 0, st, M, Z, mu_e, lv_e, mu_p, lv_p, eps, z, kld_row);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_vae_bwd(int64_t M, int Z, const float *mu_e, const float *lv_e, const float *mu_p, const float *lv_p,
+                                   const float *eps, const float *dz, const float *g_kld, float scale, float *dmu_e, float *dlv_e,
+                                   float *dmu_p, float *dlv_p, hipStream_t st) {
+    if (M * Z == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::vae_bwd_kernel, T_GRID(M * Z), 0, st, M, Z, mu_e, lv_e, mu_p, lv_p, eps, dz, g_kld, scale, dmu_e, dlv_e, dmu_p, dlv_p);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_nll_fwd(int64_t M, int X, const float *mu, const float *lv, const float *x, float *nll_row, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::nll_fwd_kernel, T_GRID(M), 0, st, M, X, mu, lv, x, nll_row);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_nll_bwd(int64_t M, int X, const float *mu, const float *lv, const float *x, const float *g, float scale,
+                                   float *dmu, float *dlv, hipStream_t st) {
+    if (M * X == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::nll_bwd_kernel, T_GRID(M * X), 0, st, M, X, mu, lv, x, g, scale, dmu, dlv);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_ce_fwd(int64_t M, const float *p, int64_t ldp, const int32_t *goal, float *ce_row, hipStream_t st) {
+    if (M == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::ce_fwd_kernel, T_GRID(M), 0, st, M, p, ldp, goal, ce_row);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_ce_bwd(int64_t M, int G, const int32_t *goal, const float *g, float *dp, int64_t ldp, hipStream_t st) {
+    if (M * G == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::ce_bwd_kernel, T_GRID(M * G), 0, st, M, G, goal, g, dp, ldp);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_sum(int64_t n, const float *x, float scale, float *out, int accumulate, hipStream_t st) {
+    hipLaunchKernelGGL(tops::sum_kernel, dim3(1), dim3(1024), 0, st, n, x, scale, out, accumulate);
+    return hipGetLastError();
+}
+
+static int col_splits(int64_t M) {
+    int64_t s = (M + 1023) / 1024;
+    return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+}
+// floats of workspace the column reductions need for a matrix with N columns
+extern "C" int64_t dn_t_col_workspace(int64_t M, int N) { return (int64_t)col_splits(M) * 2 * N; }
+
+template <int MODE>
+static hipError_t col_reduce(int64_t M, int N, const float *X, int64_t ldx, const float *stat, const float *dOut, int64_t ldd,
+                             const float *Out, int64_t ldo, int tanh_out, float *part, float scale, float *out0, float *out1,
+                             int accumulate, hipStream_t st) {
+    const int splits = col_splits(M);
+    const int rows = (int)((M + splits - 1) / splits);
+    hipLaunchKernelGGL((tops::col_reduce_kernel<MODE>), dim3((N + 63) / 64, splits), dim3(256), 0, st, M, N, rows, X, ldx, stat, dOut, ldd,
+                       Out, ldo, tanh_out, part);
+    hipLaunchKernelGGL(tops::col_finish_kernel, T_GRID(N), 0, st, N, splits, part, scale, out0, out1, accumulate);
+    return hipGetLastError();
+}
+
+// out[c] (+)= sum_m X[m][c]
+extern "C" hipError_t dn_t_colsum(int64_t M, int N, const float *X, int64_t ldx, float *out, int accumulate, float *part, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    return col_reduce<0>(M, N, X, ldx, nullptr, nullptr, 0, nullptr, 0, 0, part, 1.0f, out, nullptr, accumulate, st);
+}
+
+// BatchNorm1d forward in train mode (+ tanh).  stat [2N] receives mean | invstd (saved for the backward);
+// tmp [2N] scratch; running statistics are updated in place when given.
+extern "C" hipError_t dn_t_bn_fwd(int64_t M, int N, const float *X, int64_t ldx, const float *gamma, const float *beta, float eps,
+                                  float momentum, int tanh_out, float *Y, int64_t ldy, float *stat, float *run_mean, float *run_var,
+                                  float *tmp, float *part, hipStream_t st) {
+    if (M == 0 || N == 0) return hipSuccess;
+    hipError_t e = col_reduce<0>(M, N, X, ldx, nullptr, nullptr, 0, nullptr, 0, 0, part, 1.0f / (float)M, tmp, nullptr, 0, st);
+    if (e != hipSuccess) return e;
+    e = col_reduce<1>(M, N, X, ldx, tmp, nullptr, 0, nullptr, 0, 0, part, 1.0f, tmp + N, nullptr, 0, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tops::bn_stat_kernel, T_GRID(N), 0, st, N, M, tmp, tmp + N, eps, momentum, stat, run_mean, run_var);
+    hipLaunchKernelGGL(tops::bn_apply_kernel, T_GRID(M * N), 0, st, M, N, X, ldx, stat, gamma, beta, tanh_out, Y, ldy);
+    return hipGetLastError();
+}
+
+// -> dX, dgamma (+)=, dbeta (+)=.  sums [2N] scratch.
+extern "C" hipError_t dn_t_bn_bwd(int64_t M, int N, const float *X, int64_t ldx, const float *stat, const float *gamma, const float *dOut,
+                                  int64_t ldd, const float *Out, int64_t ldo, int tanh_out, float *dX, int64_t ldg, float *dgamma,
+                                  float *dbeta, int accumulate, float *sums, float *part, hipStream_t st) {
+    if (M == 0 || N == 0) return hipSuccess;
+    hipError_t e = col_reduce<2>(M, N, X, ldx, stat, dOut, ldd, Out, ldo, tanh_out, part, 1.0f, sums, sums + N, 0, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tops::bn_bwd_kernel, T_GRID(M * N), 0, st, M, N, X, ldx, stat, gamma, dOut, ldd, Out, ldo, tanh_out, sums, dX, ldg);
+    e = dn_t_copy2d(1, N, sums, N, dbeta, N, accumulate, st);
+    if (e != hipSuccess) return e;
+    return dn_t_copy2d(1, N, sums + N, N, dgamma, N, accumulate, st);
+}
+
+extern "C" int64_t dn_t_gat_lds_bytes(int n_max, int F, int backward) {
+    const int64_t n = n_max;
+    return sizeof(float) * (backward ? 3 * n * F + 4 * n + 2 * n * n : n * F + 2 * n + n * n);
+}
+extern "C" hipError_t dn_t_gat_attn_fwd(const int32_t *scene_ptr, const int64_t *off_compact, int S, int n_max, int64_t adj_ld, const float *adj,
+                                        const float *Wh, int64_t ldw, const float *a, int H, int F, float alpha, int elu, float *Out,
+                                        int64_t ldo, hipStream_t st) {
+    if (S == 0) return hipSuccess;
+    const int64_t lds = dn_t_gat_lds_bytes(n_max, F, 0);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    tops::Scenes sc{scene_ptr, off_compact, S, adj_ld};
+    hipLaunchKernelGGL(tops::gat_attn_fwd_kernel, dim3(S, H), dim3(128), (size_t)lds, st, sc, adj, Wh, ldw, a, F, alpha, elu, Out, ldo);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_gat_attn_bwd(const int32_t *scene_ptr, const int64_t *off_compact, int S, int n_max, int64_t adj_ld, const float *adj,
+                                        const float *Wh, int64_t ldw, const float *a, int H, int F, float alpha, int elu, const float *Out,
+                                        int64_t ldo, const float *dOut, int64_t ldd, float *dWh, int64_t ldg, float *da, hipStream_t st) {
+    if (S == 0) return hipSuccess;
+    const int64_t lds = dn_t_gat_lds_bytes(n_max, F, 1);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    tops::Scenes sc{scene_ptr, off_compact, S, adj_ld};
+    hipLaunchKernelGGL(tops::gat_attn_bwd_kernel, dim3(S, H), dim3(128), (size_t)lds, st, sc, adj, Wh, ldw, a, F, alpha, elu, Out, ldo, dOut,
+                       ldd, dWh, ldg, da);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_adj_matmul(const int32_t *scene_ptr, const int64_t *off_compact, const int32_t *row_scene, int S, int64_t Nrows,
+                                      int F, int64_t adj_ld, const float *adj, const float *X, int64_t ldx, const float *bias, int transpose, float *Y,
+                                      int64_t ldy, hipStream_t st) {
+    if (Nrows * F == 0) return hipSuccess;
+    tops::Scenes sc{scene_ptr, off_compact, S, adj_ld};
+    hipLaunchKernelGGL(tops::adj_matmul_kernel, T_GRID(Nrows * F), 0, st, sc, row_scene, Nrows, F, adj, X, ldx, bias, transpose, Y, ldy);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_disposition(const int32_t *scene_ptr, const int64_t *off_compact, const int32_t *row_scene, int S, int64_t Nrows,
+                                       int D, const float *pos, float *out, int64_t ldo, hipStream_t st) {
+    if (Nrows * D == 0) return hipSuccess;
+    tops::Scenes sc{scene_ptr, off_compact, S, 0};
+    hipLaunchKernelGGL(tops::disposition_kernel, T_GRID(Nrows * D), 0, st, sc, row_scene, Nrows, D, pos, out, ldo);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_sumsq(int64_t n, const float *g, double *acc, hipStream_t st) {
+    hipLaunchKernelGGL(tops::sumsq_kernel, dim3(1), dim3(1024), 0, st, n, g, acc);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_adam(int64_t n, float *p, float *g, float *m, float *v, const double *sumsq, float clip, float lr, float b1,
+                                float b2, float eps, float bc1, float bc2, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::adam_kernel, T_GRID(n), 0, st, n, p, g, m, v, sumsq, clip, lr, b1, b2, eps, bc1, bc2);
+    return hipGetLastError();
+}

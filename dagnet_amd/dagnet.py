@@ -63,6 +63,8 @@ class DAGNet(RolloutModule):
         sp, a, dense = resolve_adj(adj_out, traj.shape[1], seq_start_end)
         goals = as_goal_index(goals_ohe, self.g_dim)
         losses, h = self._run_forward(sp, traj_rel, traj=traj, goals=goals, adj=a, adj_dense=dense, eps=eps, seed=seed)
+        if isinstance(losses, tuple):
+            return losses[0], losses[1], losses[2], h
         return losses[0:1], losses[1:2], losses[2:3], h
 
     def sample(self, samples_seq_len, h, x_abs_start, g_start, seq_start_end, eps=None, q=None, seed=None):

@@ -1,0 +1,154 @@
+"""The differentiable (train-mode) forward of the three models and one training step (row T):
+models/dagnet/model.py:138-194, models/avrnn/model.py:93-143, models/baseline/model.py:70-115 and
+models/dagnet/train_bsk.py:259-291.
+
+Layer by layer over all N rows of the batch: every layer is an operator of dagnet_amd._ops (HIP forward and backward);
+torch only allocates, keeps the autograd tape and adds up the per-step loss scalars.  BatchNorm uses batch statistics
+over all rows of the batch (gat_model.py:21 in train mode) and updates its running statistics like nn.BatchNorm1d.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import _capi, _ops
+from ._ops import ACT_LRELU, ACT_NONE, ACT_RELU, CeFn, NllFn, SoftmaxFn, VaeFn, gat_train, gcn_train, gru_step, linear
+
+_PLANS: "OrderedDict[tuple, _capi.HipPlan]" = OrderedDict()
+
+
+def table_plan(scene_ptr, device) -> _capi.HipPlan:
+    """Scene tables only (no packed weights: the training operators read the live parameters)."""
+    sp = np.ascontiguousarray(np.asarray(scene_ptr, dtype=np.int32))
+    key = (torch.device(device).index or 0, sp.tobytes())
+    plan = _PLANS.get(key)
+    if plan is None:
+        plan = _capi.HipPlan(None, sp, 1, device=device)
+        _PLANS[key] = plan
+        while len(_PLANS) > 8:
+            _PLANS.popitem(last=False)
+    else:
+        _PLANS.move_to_end(key)
+    return plan
+
+
+def _mlp2(seq, xs, cols, gidx=None, gcol=0):
+    h = linear(seq[0], xs, cols, act=ACT_LRELU, gidx=gidx, gcol=gcol)
+    return linear(seq[2], [h], [0], act=ACT_LRELU)
+
+
+def _graph(mod, x, adj_t, plan):
+    from .gat import GAT
+    return gat_train(mod, x, adj_t, plan) if isinstance(mod, GAT) else gcn_train(mod, x, adj_t, plan)
+
+
+def _eps(eps, t, N, Z, device):
+    if eps is not None:
+        return eps[t - 1].contiguous()
+    return torch.rand((N, Z), dtype=torch.float32, device=device)      # torch.rand_like in the reference (model.py:118-121)
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, eps=None):
+    """-> (KLD[1], NLL[1], CE[1], h[L,N,R]); differentiable w.r.t. the parameters of ``model``."""
+    kind = {"VRNN": "vrnn", "AVRNN": "avrnn", "DAGNet": "dagnet"}[type(model).__name__]
+    dev = traj_rel.device
+    if not traj_rel.is_cuda:
+        raise _capi.DagnetHipError("the training step needs a ROCm device; there is no CPU path")
+    T, N, _ = traj_rel.shape
+    R, H, Z, L = model.rnn_dim, model.h_dim, model.z_dim, model.n_layers
+    traj_rel = _f32(traj_rel)
+    plan = table_plan(scene_ptr, dev) if kind != "vrnn" else None
+    if kind == "dagnet":
+        G, D = model.g_dim, model.d_dim
+        traj = _f32(traj)
+        goals = goals.to(torch.int32).contiguous()
+    if eps is not None:
+        eps = _f32(eps)
+    h = [torch.zeros((N, R), dtype=torch.float32, device=dev) for _ in range(L)]
+    zero = torch.zeros(1, dtype=torch.float32, device=dev)
+    kld, nll, ce = zero, zero, zero
+    for t in range(1, T):
+        x_t = traj_rel[t]
+        hl = h[-1]
+        if kind == "dagnet":
+            d_t = _ops.disposition(plan, traj[t], D)
+            g_prev, g_t = goals[t - 1], goals[t]
+            hid = linear(model.dec_goal[0], [d_t, hl], [0, D], act=ACT_RELU, gidx=g_prev, gcol=D + R)
+            dec_g = SoftmaxFn.apply(linear(model.dec_goal[2], [hid], [0]))
+            g_graph = _graph(model.graph_goals, dec_g, adj[t], plan)
+            g_comb = SoftmaxFn.apply(linear(model.lg_goals[0], [dec_g, g_graph], [0, G]))
+            ce = ce + CeFn.apply(g_comb, g_t)
+            phi_x = _mlp2(model.phi_x, [x_t], [0])
+            enc = _mlp2(model.enc, [phi_x, hl], [0, H + G], gidx=g_t, gcol=H)
+            prior = _mlp2(model.prior, [hl], [G], gidx=g_t, gcol=0)
+        else:
+            phi_x = _mlp2(model.phi_x, [x_t], [0])
+            enc = _mlp2(model.enc, [phi_x, hl], [0, H])
+            prior = _mlp2(model.prior, [hl], [0])
+        mu_e, lv_e = linear(model.enc_mean, [enc], [0]), linear(model.enc_logvar, [enc], [0])
+        mu_p, lv_p = linear(model.prior_mean, [prior], [0]), linear(model.prior_logvar, [prior], [0])
+        z, k = VaeFn.apply(mu_e, lv_e, mu_p, lv_p, _eps(eps, t, N, Z, dev))
+        phi_z = _mlp2(model.phi_z, [z], [0])
+        if kind == "dagnet":
+            dec = _mlp2(model.dec, [d_t, phi_z, hl], [0, D + G, D + G + H], gidx=g_t, gcol=D)
+        else:
+            dec = _mlp2(model.dec, [phi_z, hl], [0, H])
+        mu_d, lv_d = linear(model.dec_mean, [dec], [0]), linear(model.dec_logvar, [dec], [0])
+        h = gru_step(model.rnn, [phi_x, phi_z], [0, H], h)
+        kld = kld + k
+        nll = nll + NllFn.apply(mu_d, lv_d, x_t)
+        if kind != "vrnn":
+            graph = model.graph_hiddens if kind == "dagnet" else model.graph
+            blend = model.lg_hiddens if kind == "dagnet" else model.lg
+            h_g = _graph(graph, h[-1], adj[t], plan)
+            h[-1] = linear(blend, [h_g, h[-1]], [0, R])
+    return kld, nll, ce, torch.stack(h, 0)
+
+
+def train_step(model, optimizer: "_ops.ClipAdam", batch, kld_weight=1.0, ce_weight=1.0, eps=None):
+    """The reference's training step (train_bsk.py:259-291): zero_grad, train-mode forward, loss = kld_weight KLD + NLL
+    (+ ce_weight CE), backward, clip_grad_norm_ + Adam (both inside ``optimizer.step()``).
+
+    batch: VRNN (x_rel,) | A-VRNN (x_rel, adj[, seq_start_end]) | DAG-Net (traj, traj_rel, goals_ohe, seq_start_end, adj).
+    -> dict(loss, kld, nll, ce) of [1] device tensors (no host synchronisation)."""
+    model.train()
+    optimizer.zero_grad()
+    name = type(model).__name__
+    if name == "VRNN":
+        kld, nll, _ = model(batch[0], eps=eps)
+        ce = torch.zeros_like(kld)
+        loss = kld_weight * kld + nll
+    elif name == "AVRNN":
+        kld, nll, _ = model(batch[0], batch[1], seq_start_end=batch[2] if len(batch) > 2 else None, eps=eps)
+        ce = torch.zeros_like(kld)
+        loss = kld_weight * kld + nll
+    else:
+        kld, nll, ce, _ = model(*batch, eps=eps)
+        loss = kld_weight * kld + nll + ce_weight * ce
+    loss.backward()
+    optimizer.step()
+    return dict(loss=loss.detach(), kld=kld.detach(), nll=nll.detach(), ce=ce.detach())
+
+
+def allreduce_gradients(params, world_size=None):
+    """Data-parallel training: one flat all-reduce(SUM) of every gradient over the ranks (RCCL over xGMI),
+    between backward() and the optimizer step.  Scenes are sharded, weights replicated; the losses are sums over rows,
+    so gradients add up (no averaging), exactly as one rank seeing the whole batch -- except BatchNorm, whose batch
+    statistics stay per shard (documented deviation)."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized() or (world_size or dist.get_world_size()) == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n

@@ -175,6 +175,96 @@ int dagnet_displacement_errors(int32_t T, int32_t N, const float *d_pred, const 
 int dagnet_categorical(int32_t N, int32_t G, const float *d_weights, const float *d_q, uint64_t seed,
                        int32_t *d_out, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Training-step operators.  The reference's training step is torch autograd over
+ * DAGNet.forward / AVRNN.forward / VRNN.forward in train() mode (models/dagnet/train_bsk.py:259-291,
+ * models/dagnet/model.py:138-194).  These are the forward and hand-written backward kernels of every
+ * layer of that pass; dagnet_amd/_ops.py binds each pair into one torch.autograd.Function.
+ * All matrices: device fp32, row-major, explicit row stride (ld*, in floats).  Every function returns a
+ * dagnet_status and launches on `stream` without synchronising.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Replaces: nn.Linear forward/backward (F.linear and its autograd; models/dagnet/model.py:60-116) and the
+ * x @ W products of the graph layers (gat_layers.py:26, gcn_layers.py:21).
+ * C[M,N] = act([C +] A[M,K] op(B) + bias + gather[gidx[m]*gs_g + n*gs_n]); op(B) = B[N,K]^T (transb 0) or B[K,N]
+ * (transb 1).  act: 0 none, 1 LeakyReLU(slope), 2 tanh, 3 ReLU.  One-hot inputs are the gather term. */
+int dagnet_op_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int32_t transb, const float *bias, float *C,
+                   int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, float slope, int32_t accumulate,
+                   const float *gather, const int32_t *gidx, int64_t gs_g, int64_t gs_n, void *stream);
+/* Weight gradients: C[N,K] (+)= A[M,N]^T B[M,K], deterministic two-pass reduction over the rows.
+ * workspace: dagnet_op_gemm_tn_workspace(M, N, K) floats. */
+int64_t dagnet_op_gemm_tn_workspace(int32_t M, int32_t N, int32_t K);
+int dagnet_op_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int32_t M, int32_t N,
+                      int32_t K, float *workspace, int32_t accumulate, void *stream);
+/* dP = dY * act'(.) through the saved layer output Y (backward of LeakyReLU / ReLU / tanh). */
+int dagnet_op_act_bwd(int64_t M, int32_t N, const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp,
+                      int32_t act, float slope, void *stream);
+/* dst (+)= src for an [M,N] block (concatenations and their backward). */
+int dagnet_op_copy2d(int64_t M, int32_t N, const float *src, int64_t lds, float *dst, int64_t ldd, int32_t accumulate,
+                     void *stream);
+/* Gradient of the weight columns behind a one-hot input: dW[n][gidx[m]] += dP[m][n]. */
+int dagnet_op_onehot_grad(int64_t M, int32_t N, const float *dP, int64_t ldp, const int32_t *gidx, float *dW, int64_t ldw,
+                          void *stream);
+/* Replaces: nn.Softmax(dim=-1) in dec_goal / lg_goals (models/dagnet/model.py:66,100) and its backward. */
+int dagnet_op_softmax_fwd(int64_t M, int32_t N, const float *X, int64_t ldx, float *Y, int64_t ldy, void *stream);
+int dagnet_op_softmax_bwd(int64_t M, int32_t N, const float *Y, int64_t ldy, const float *dY, int64_t ldd, float *dX, int64_t ldx,
+                          void *stream);
+/* Replaces: the gate arithmetic of nn.GRU (models/dagnet/model.py:116,185); gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh
+ * [M,3R] come from dagnet_op_gemm.  gates [M,3R] keeps r, z, n for the backward. */
+int dagnet_op_gru_fwd(int64_t M, int32_t R, const float *gi, const float *gh, const float *h, float *hn, float *gates, void *stream);
+int dagnet_op_gru_bwd(int64_t M, int32_t R, const float *dhn, const float *gates, const float *gh, const float *h, float *dgi,
+                      float *dgh, float *dh, void *stream);
+/* Replaces: _reparameterize + _kld (models/dagnet/model.py:118-128): z = eps exp(logvar_e / 2) + mean_e, kld_row[m] =
+ * per-row KLD (the caller takes the mean with dagnet_op_sum); backward from dz and the scalar gradient g_kld[0] * scale. */
+int dagnet_op_vae_fwd(int64_t M, int32_t Z, const float *mu_e, const float *lv_e, const float *mu_p, const float *lv_p,
+                      const float *eps, float *z, float *kld_row, void *stream);
+int dagnet_op_vae_bwd(int64_t M, int32_t Z, const float *mu_e, const float *lv_e, const float *mu_p, const float *lv_p,
+                      const float *eps, const float *dz, const float *g_kld, float scale, float *dmu_e, float *dlv_e,
+                      float *dmu_p, float *dlv_p, void *stream);
+/* Replaces: _nll_gauss (models/dagnet/model.py:130-135), per row, and its backward. */
+int dagnet_op_nll_fwd(int64_t M, int32_t X, const float *mu, const float *lv, const float *x, float *nll_row, void *stream);
+int dagnet_op_nll_bwd(int64_t M, int32_t X, const float *mu, const float *lv, const float *x, const float *g, float scale,
+                      float *dmu, float *dlv, void *stream);
+/* Replaces: cross_entropy -= sum(g_t * g_combined) (models/dagnet/model.py:162): ce_row[m] = -p[m][goal[m]]. */
+int dagnet_op_ce_fwd(int64_t M, const float *p, int64_t ldp, const int32_t *goal, float *ce_row, void *stream);
+int dagnet_op_ce_bwd(int64_t M, int32_t G, const int32_t *goal, const float *g, float *dp, int64_t ldp, void *stream);
+/* out[0] (+)= scale * sum(x) in fp64, fixed order (loss scalars). */
+int dagnet_op_sum(int64_t n, const float *x, float scale, float *out, int32_t accumulate, void *stream);
+/* Column sums over the rows (bias gradients): out[c] (+)= sum_m X[m][c]; workspace: dagnet_op_col_workspace(M, N) floats. */
+int64_t dagnet_op_col_workspace(int64_t M, int32_t N);
+int dagnet_op_colsum(int64_t M, int32_t N, const float *X, int64_t ldx, float *out, int32_t accumulate, float *workspace,
+                     void *stream);
+/* Replaces: nn.BatchNorm1d in train() mode followed by tanh (gat_model.py:21-22, gcn_model.py:15-19): batch statistics
+ * over all M rows, running statistics updated in place (momentum, unbiased variance).  stat [2N] keeps mean | invstd,
+ * tmp [2N] and sums [2N] are scratch. */
+int dagnet_op_bn_fwd(int64_t M, int32_t N, const float *X, int64_t ldx, const float *gamma, const float *beta, float eps,
+                     float momentum, int32_t tanh_out, float *Y, int64_t ldy, float *stat, float *run_mean, float *run_var,
+                     float *tmp, float *workspace, void *stream);
+int dagnet_op_bn_bwd(int64_t M, int32_t N, const float *X, int64_t ldx, const float *stat, const float *gamma, const float *dOut,
+                     int64_t ldd, const float *Out, int64_t ldo, int32_t tanh_out, float *dX, int64_t ldg, float *dgamma,
+                     float *dbeta, int32_t accumulate, float *sums, float *workspace, void *stream);
+/* Replaces: GraphAttentionLayer.forward (gat_layers.py:25-40) after Wh = x W, per scene of the plan, for H heads of width F
+ * stacked along the columns of Wh; a [H][2F].  adj: compact block-diagonal (adj_ld 0) or dense [N,N] (adj_ld N).
+ * Backward: dWh and da (accumulated over the scenes with atomics; da must be zeroed by the caller). */
+int dagnet_op_gat_attn_fwd(const dagnet_plan *p, const float *adj, int64_t adj_ld, const float *Wh, int64_t ldw, const float *a,
+                           int32_t H, int32_t F, float alpha, int32_t elu, float *Out, int64_t ldo, void *stream);
+int dagnet_op_gat_attn_bwd(const dagnet_plan *p, const float *adj, int64_t adj_ld, const float *Wh, int64_t ldw, const float *a,
+                           int32_t H, int32_t F, float alpha, int32_t elu, const float *Out, int64_t ldo, const float *dOut,
+                           int64_t ldd, float *dWh, int64_t ldg, float *da, void *stream);
+/* Replaces: torch.spmm(adj, support) + bias of GraphConvolution.forward (gcn_layers.py:20-26) per scene; transpose = 1
+ * multiplies by adj^T (the backward). */
+int dagnet_op_adj_matmul(const dagnet_plan *p, int32_t F, const float *adj, int64_t adj_ld, const float *X, int64_t ldx,
+                         const float *bias, int32_t transpose, float *Y, int64_t ldy, void *stream);
+/* Replaces: the disposition tensor d of DAGNet.forward (models/dagnet/model.py:141-147) for one timestep: out[r] = flattened
+ * xy of the agents of r's scene, zero padded to D columns. */
+int dagnet_op_disposition(const dagnet_plan *p, int32_t D, const float *pos, float *out, int64_t ldo, void *stream);
+/* Replaces: torch.nn.utils.clip_grad_norm_ + torch.optim.Adam.step (models/dagnet/train_bsk.py:289-290).
+ * dagnet_op_sumsq: acc[0] += sum g^2 (fp64).  dagnet_op_adam: g *= min(1, clip / (sqrt(sumsq[0]) + 1e-6)) (clip <= 0: off),
+ * then the Adam update of p with moments m, v at step `step` (1-based). */
+int dagnet_op_sumsq(int64_t n, const float *g, double *acc, void *stream);
+int dagnet_op_adam(int64_t n, float *p, float *g, float *m, float *v, const double *sumsq, float clip, float lr, float beta1,
+                   float beta2, float eps, int32_t step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

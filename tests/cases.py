@@ -85,7 +85,11 @@ def list_train_cases():
     return list_cases(("train_",))
 
 
-GRAD_RTOL = 2e-4          # per-parameter gradient: |got - want| <= GRAD_RTOL * max|want| + GRAD_ATOL
+# per-parameter gradient: |got - want| <= GRAD_RTOL * max|want| + GRAD_ATOL (+ 1e-6 of the total norm).
+# Calibration: on train_dagnet_bsk_gat_n5 the reference's own fp32 gradients sit 1.5e-4 .. 4e-4 (relative to max|g|) away from
+# an fp64 evaluation of the same step (train-mode BatchNorm over 15 rows is ill-conditioned), so 1e-3 is ~3x the fixture's
+# own rounding noise; a wrong formula (slope, gate order, a missing 1/N) shows up at >= 1e-2.
+GRAD_RTOL = 1e-3
 GRAD_ATOL = 2e-6
 
 

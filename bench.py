@@ -54,6 +54,9 @@ WORKLOADS = {
                                data="sdd", g_cells=(32, 30)),
     # configs[0] shape on the GPU: VRNN baseline
     "vrnn_bsk_4096x20": dict(kind="vrnn", scenes=4096, agents=10, K=20, obs=10, pred=40, args=dict(n_layers=2)),
+    # configs[4], training leg (row T): one optimizer step of DAG-Net on a chunk of scenes, full 50-step sequence
+    "train_dagnet_bsk_1024": dict(kind="dagnet", scenes=1024, agents=10, K=1, obs=10, pred=40, args=dict(n_layers=2), train=True),
+    "train_dagnet_bsk_8192": dict(kind="dagnet", scenes=8192, agents=10, K=1, obs=10, pred=40, args=dict(n_layers=2), train=True),
 }
 
 
@@ -136,6 +139,112 @@ def cpu_baseline(wl, budget_s=20.0):
                 sample=f"{scenes} scenes x {n} agents x {done} samples x {T} steps, dense-graph oracle, torch CPU fp32")
 
 
+def train_flops_per_row_step(a, n, d_dim):
+    """Algorithmic FLOPs of one teacher-forced row-step of DAG-Net, forward + backward (backward = 2x the forward MACs:
+    input and weight gradients).  Forward = the sample() count of flops_per_row_step plus the encoder and dec_logvar."""
+    X, H, Z, R, G = a.x_dim, a.h_dim, a.z_dim, a.rnn_dim, a.g_dim
+    fwd = flops_per_row_step("dagnet", a, n, d_dim) + 2 * ((H + R) * H + H * H + 2 * H * Z + H * X)
+    return 3 * fwd
+
+
+def bench_train(opt, wl, rank, world, dev, dist):
+    """One training step = zero_grad, train-mode forward over the full sequence, backward, clip + Adam (row T)."""
+    from dagnet_amd import _ops, training
+    from dagnet_amd.adjacency_matrix import compute_adjs_distsim
+    from dagnet_amd.utils import to_goals_one_hot
+    a, model = build(wl, dev)
+    model.train()
+    S, T = wl["scenes"], wl["obs"] + wl["pred"]
+    sizes = scene_sizes(wl, seed=rank)
+    n_rows = int(sum(sizes))
+    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = [t.to(dev) for t in syn.make_batch(sizes, wl["obs"], wl["pred"], 1000 + rank)]
+    traj, rel = torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0)
+    goals = torch.cat((obs_goals, gt_goals), 0).to(torch.int32)
+    from dagnet_amd.adjacency_matrix import BlockDiagAdj
+    adj = compute_adjs_distsim(a, sse, obs, gt, compact=True)
+    optim = _ops.ClipAdam(list(model.parameters()), lr=1e-3, clip=10.0)
+    params = list(model.parameters())
+
+    frac = 1.0 / world                          # KLD / NLL are means over the rows of the shard, CE is a sum
+    eps_all = torch.empty((T - 1, n_rows, a.z_dim), dtype=torch.float32, device=dev)
+
+    def loss_fn(m, eps):
+        kld, nll, ce, _ = m(traj, rel, goals, sse, adj, eps=eps)
+        return frac * (kld + nll) + 1e-2 * ce, (kld, nll, ce)
+
+    gfb = None if opt.no_graph else training.GraphedForwardBackward(model, loss_fn, [eps_all])
+
+    def step():
+        eps_all.uniform_()                      # torch.rand_like of the reference's _reparameterize, drawn for all steps at once
+        if gfb is not None:
+            loss, _ = gfb(eps_all)
+        else:
+            optim.zero_grad()
+            loss, _ = loss_fn(model, eps_all)
+            loss.backward()
+        training.allreduce_gradients(params)
+        optim.step()
+        return loss
+
+    for _ in range(opt.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(opt.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    if rank != 0:
+        return
+    flop = train_flops_per_row_step(a, wl["agents"], 2 * wl["agents"]) * n_rows * (T - 1)
+    achieved = flop / (dt / opt.steps) / 1e12
+    line = {
+        "metric": "training trajectories/sec (one optimizer step, teacher-forced 50-step sequences)",
+        "value": n_rows * world * opt.steps / dt, "unit": "trajectories/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
+        "ms_per_step": dt / opt.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": opt.workload, "model": "dagnet", "scenes_per_gpu": S, "agents_per_scene": wl["agents"], "seq_len": T,
+                   "rows_per_gpu": n_rows, "parallelism": f"scenes sharded x{world}, one all-reduce of 184 350 fp32 gradients per step"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                     "kernel": "layer-by-layer operators (gemm_nt_kernel + train_ops.hip), launch-bound at this batch"},
+        "loss": float(loss.detach()),
+    }
+    if not opt.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_train_baseline(wl)
+    print(json.dumps(line), flush=True)
+
+
+def cpu_train_baseline(wl):
+    """The oracle's training step (torch CPU autograd over the dense-graph restatement) on 32 scenes."""
+    from oracle import dagnet_oracle as orc
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    scenes, n = 32, wl["agents"]
+    a = syn.make_args(obs_len=wl["obs"], pred_len=wl["pred"], **wl["args"])
+    sd = syn.random_state_dict(dagnet_amd.DAGNet(a, n), 128)
+    cfg = orc.make_cfg(n_max_agents=n, **{k: getattr(a, k) for k in ("x_dim", "h_dim", "z_dim", "rnn_dim", "n_layers", "g_dim", "graph_model",
+                                                                        "graph_hid", "adjacency_type", "top_k_neigh", "sigma", "alpha",
+                                                                        "n_heads")})
+    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = syn.make_batch([n] * scenes, wl["obs"], wl["pred"], 1)
+    traj, rel = torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0)
+    goals = orc.one_hot(torch.cat((obs_goals, gt_goals), 0).long(), a.g_dim)
+    adj = orc.adjacency_seq(cfg, sse, traj)
+    eps = syn.uniform_noise(1, "eps", (traj.shape[0] - 1, traj.shape[1], a.z_dim))
+    t0 = time.perf_counter()
+    orc.train_step(sd, cfg, "dagnet", (traj, rel, goals, sse, adj), eps)
+    dt = time.perf_counter() - t0
+    return dict(value=scenes * n / dt, unit="trajectories/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"one training step on {scenes} scenes x {n} agents x {traj.shape[0]} steps, dense-graph oracle, torch CPU autograd")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -143,6 +252,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="dagnet_bsk_4096x20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="training workloads: issue every launch from the host instead of replaying a hipGraph")
     opt = ap.parse_args()
     wl = WORKLOADS[opt.workload]
 
@@ -159,6 +269,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    if wl.get("train"):
+        bench_train(opt, wl, rank, world, dev, dist)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
     a, model = build(wl, dev)
     S, K, T = wl["scenes"], wl["K"], wl["pred"]
     sizes = scene_sizes(wl, seed=rank)

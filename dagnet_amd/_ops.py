@@ -41,7 +41,7 @@ def _lib():
         lib.dagnet_op_gemm_tn.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, vp]
         lib.dagnet_op_act_bwd.argtypes = [i64, i32, vp, i64, vp, i64, vp, i64, i32, f32, vp]
         lib.dagnet_op_copy2d.argtypes = [i64, i32, vp, i64, vp, i64, i32, vp]
-        lib.dagnet_op_onehot_grad.argtypes = [i64, i32, vp, i64, vp, vp, i64, vp]
+        lib.dagnet_op_onehot_grad.argtypes = [i64, i32, i32, vp, i64, vp, vp, i64, vp, vp]
         lib.dagnet_op_softmax_fwd.argtypes = [i64, i32, vp, i64, vp, i64, vp]
         lib.dagnet_op_softmax_bwd.argtypes = [i64, i32, vp, i64, vp, i64, vp, i64, vp]
         lib.dagnet_op_gru_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp]
@@ -155,7 +155,7 @@ class LinearFn(torch.autograd.Function):
     concatenation of dense pieces and (optionally) one one-hot piece given by its index (never materialised)."""
 
     @staticmethod
-    def forward(ctx, W, b, act, slope, cols, gidx, gcol, *xs):
+    def forward(ctx, W, b, act, slope, cols, gidx, gcol, gdim, *xs):
         N, Ktot = W.shape
         M = xs[0].shape[0]
         y = _empty(M, N, xs[0])
@@ -170,13 +170,13 @@ class LinearFn(torch.autograd.Function):
             else:
                 gemm(x, Wp, y, bias=b if fin else None, act=act if fin else ACT_NONE, slope=slope, accumulate=s > 0)
         ctx.save_for_backward(W, y, gidx, *xs)
-        ctx.meta = (act, slope, tuple(cols), gcol, b is not None)
+        ctx.meta = (act, slope, tuple(cols), gcol, gdim, b is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         W, y, gidx, *xs = ctx.saved_tensors
-        act, slope, cols, gcol, has_b = ctx.meta
+        act, slope, cols, gcol, gdim, has_b = ctx.meta
         N, Ktot = W.shape
         M = y.shape[0]
         dy = _rows(dy)
@@ -193,25 +193,27 @@ class LinearFn(torch.autograd.Function):
                 gemm_tn(dpre, x, dW[:, c0:c0 + x.shape[1]])
             if gidx is not None:
                 (dp, ldp) = _m(dpre)
-                _check(_lib().dagnet_op_onehot_grad(M, N, dp, ldp, _p(gidx), C.c_void_p(dW.data_ptr() + 4 * gcol), Ktot,
+                ws = _ws(y.device, _lib().dagnet_op_gemm_tn_workspace(M, N, gdim))
+                _check(_lib().dagnet_op_onehot_grad(M, N, gdim, dp, ldp, _p(gidx), C.c_void_p(dW.data_ptr() + 4 * gcol), Ktot, _p(ws),
                                                     _stream(y.device)))
         if has_b and ctx.needs_input_grad[1]:
             db = torch.empty(N, dtype=torch.float32, device=y.device)
             colsum(dpre, db)
         dxs = []
         for i, (x, c0) in enumerate(zip(xs, cols)):
-            if ctx.needs_input_grad[7 + i]:
+            if ctx.needs_input_grad[8 + i]:
                 dx = _empty(M, x.shape[1], y)
                 gemm(dpre, W[:, c0:c0 + x.shape[1]], dx, transb=True, K=N)
                 dxs.append(dx)
             else:
                 dxs.append(None)
-        return (dW, db, None, None, None, None, None, *dxs)
+        return (dW, db, None, None, None, None, None, None, *dxs)
 
 
-def linear(mod, xs: Sequence[torch.Tensor], cols: Sequence[int], act=ACT_NONE, slope=0.01, gidx=None, gcol=0):
-    """nn.Linear ``mod`` applied to [x_0 | ... | one-hot(gidx)] with x_s at input columns cols[s] and the one-hot block at gcol."""
-    return LinearFn.apply(mod.weight, mod.bias, act, slope, tuple(cols), gidx, gcol, *xs)
+def linear(mod, xs: Sequence[torch.Tensor], cols: Sequence[int], act=ACT_NONE, slope=0.01, gidx=None, gcol=0, gdim=0):
+    """nn.Linear ``mod`` applied to [x_0 | ... | one-hot(gidx)] with x_s at input columns cols[s] and the one-hot block (gdim wide)
+    at column gcol."""
+    return LinearFn.apply(mod.weight, mod.bias, act, slope, tuple(cols), gidx, gcol, gdim, *xs)
 
 
 class MatmulFn(torch.autograd.Function):
@@ -515,10 +517,10 @@ def gru_step(rnn: torch.nn.GRU, xs, cols, h_layers):
         Wih, Whh = getattr(rnn, f"weight_ih_l{l}"), getattr(rnn, f"weight_hh_l{l}")
         bih, bhh = getattr(rnn, f"bias_ih_l{l}"), getattr(rnn, f"bias_hh_l{l}")
         if l == 0:
-            gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, tuple(cols), None, 0, *xs)
+            gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, tuple(cols), None, 0, 0, *xs)
         else:
-            gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, (0,), None, 0, out[-1])
-        gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, h_layers[l])
+            gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, (0,), None, 0, 0, out[-1])
+        gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, 0, h_layers[l])
         out.append(GruCellFn.apply(gi, gh, h_layers[l]))
     return out
 

@@ -1237,9 +1237,10 @@ extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64
 extern "C" int64_t dn_gemm_tn_workspace(int M, int N, int K);
 extern "C" hipError_t dn_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int M, int N, int K,
                                  float *part, int accumulate, hipStream_t st);
+extern "C" hipError_t dn_gemm_tn_idx(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, float *C, int64_t ldc,
+                                     int M, int N, int K, float *part, int accumulate, hipStream_t st);
 extern "C" hipError_t dn_t_act_bwd(int64_t, int, const float *, int64_t, const float *, int64_t, float *, int64_t, int, float, hipStream_t);
 extern "C" hipError_t dn_t_copy2d(int64_t, int, const float *, int64_t, float *, int64_t, int, hipStream_t);
-extern "C" hipError_t dn_t_onehot_grad(int64_t, int, const float *, int64_t, const int32_t *, float *, int64_t, hipStream_t);
 extern "C" hipError_t dn_t_softmax_fwd(int64_t, int, const float *, int64_t, float *, int64_t, hipStream_t);
 extern "C" hipError_t dn_t_softmax_bwd(int64_t, int, const float *, int64_t, const float *, int64_t, float *, int64_t, hipStream_t);
 extern "C" hipError_t dn_t_gru_fwd(int64_t, int, const float *, const float *, const float *, float *, float *, hipStream_t);
@@ -1313,10 +1314,12 @@ extern "C" int dagnet_op_copy2d(int64_t M, int32_t N, const float *src, int64_t 
     HIP_TRY(dn_t_copy2d(M, N, src, lds, dst, ldd, accumulate, OP_ST));
     return DAGNET_OK;
 }
-extern "C" int dagnet_op_onehot_grad(int64_t M, int32_t N, const float *dP, int64_t ldp, const int32_t *gidx, float *dW, int64_t ldw,
-                                     void *stream) {
-    OP_NEED(M >= 0 && N >= 0 && (M * N == 0 || (dP && gidx && dW)), "bad argument");
-    HIP_TRY(dn_t_onehot_grad(M, N, dP, ldp, gidx, dW, ldw, OP_ST));
+extern "C" int dagnet_op_onehot_grad(int64_t M, int32_t N, int32_t G, const float *dP, int64_t ldp, const int32_t *gidx, float *dW,
+                                     int64_t ldw, float *workspace, void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && G >= 0 && M <= 0x7fffffffLL && (M * N == 0 || (dP && gidx && dW && workspace)), "bad argument");
+    if (M * N == 0 || G == 0) return DAGNET_OK;
+    // dW[n][g] = sum_m dP[m][n] * onehot(gidx[m])[g]: the weight-gradient GEMM with a generated one-hot operand
+    HIP_TRY(dn_gemm_tn_idx(dP, ldp, nullptr, 0, gidx, dW, ldw, (int)M, N, G, workspace, 0, OP_ST));
     return DAGNET_OK;
 }
 extern "C" int dagnet_op_softmax_fwd(int64_t M, int32_t N, const float *X, int64_t ldx, float *Y, int64_t ldy, void *stream) {

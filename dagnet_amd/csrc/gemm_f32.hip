@@ -175,6 +175,7 @@ struct TnArgs {
     float *C; int64_t ldc;            // [splits][N, K] partial sums, split stride = N*ldc
     int M, N, K;
     int rows_per_split;               // multiple of 32
+    const int32_t *bidx;              // not null: B is one-hot, B[m][k] = (bidx[m] == k)   (gradients of one-hot inputs)
 };
 
 // C_split[n][k] = sum over this split's rows m of A[m][n] * B[m][k].  Workgroup tile 64 x 64 (2x2 waves, 1 tile each),
@@ -206,7 +207,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             ga[i] = ld4(p.A, p.lda, m + lrow + 16 * i, n0 + lc4, p.N, vecA);
-            gb[i] = ld4(p.B, p.ldb, m + lrow + 16 * i, k0 + lc4, p.K, vecB);
+            if (p.bidx) {
+                const int row = m + lrow + 16 * i;
+                const int hot = row < mend ? p.bidx[row] - (k0 + lc4) : -1;
+                gb[i] = f32x4{hot == 0 ? 1.f : 0.f, hot == 1 ? 1.f : 0.f, hot == 2 ? 1.f : 0.f, hot == 3 ? 1.f : 0.f};
+            } else {
+                gb[i] = ld4(p.B, p.ldb, m + lrow + 16 * i, k0 + lc4, p.K, vecB);
+            }
         }
     };
     auto sstore = [&](int buf) {
@@ -246,14 +253,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
 }
 
 // out[r][c] (+)= sum_s part[s][r][c]   (deterministic second pass of the split reduction; out has row stride ldc)
-__global__ void reduce_splits_kernel(const float *part, int splits, int N, int K, float *out, int64_t ldc, int accumulate) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// block = 32 outputs x 8 split lanes: coalesced 128-byte reads, fixed summation order
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float *part, int splits, int N, int K, float *out, int64_t ldc,
+                                                            int accumulate) {
+    __shared__ float red[8][32];
+    const int lo = threadIdx.x & 31, lg = threadIdx.x >> 5;
     const int64_t n = (int64_t)N * K;
-    if (i >= n) return;
-    float *dst = out + (i / K) * ldc + (i % K);
-    float s = accumulate ? *dst : 0.f;
-    for (int k = 0; k < splits; ++k) s += part[k * n + i];
-    *dst = s;
+    const int64_t i = (int64_t)blockIdx.x * 32 + lo;
+    float s = 0.f;
+    if (i < n)
+        for (int k = lg; k < splits; k += 8) s += part[k * n + i];
+    red[lg][lo] = s;
+    __syncthreads();
+    if (lg == 0 && i < n) {
+        float t = ((red[0][lo] + red[1][lo]) + (red[2][lo] + red[3][lo])) + ((red[4][lo] + red[5][lo]) + (red[6][lo] + red[7][lo]));
+        float *dst = out + (i / K) * ldc + (i % K);
+        *dst = accumulate ? *dst + t : t;
+    }
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -301,24 +317,33 @@ extern "C" hipError_t dn_gemm_nt(const float *A, int64_t lda, const float *W, in
 
 // C[N,K] (+)= A[M,N]^T B[M,K], deterministic two-pass split over M.  `part` is a workspace of
 // dn_gemm_tn_workspace(M, N, K) floats.
-extern "C" int64_t dn_gemm_tn_splits(int M) {
-    int64_t s = (M + 4095) / 4096;
-    return s < 1 ? 1 : (s > 256 ? 256 : s);
+// splits over the rows: enough workgroups to fill 256 CUs twice, at least 256 rows each
+extern "C" int64_t dn_gemm_tn_splits(int M, int N, int K) {
+    const int64_t blocks = (int64_t)((N + 63) / 64) * ((K + 63) / 64);
+    int64_t s = (384 + blocks - 1) / blocks;
+    const int64_t cap = (M + 255) / 256;
+    if (s > cap) s = cap;
+    return s < 1 ? 1 : (s > 512 ? 512 : s);
 }
-extern "C" int64_t dn_gemm_tn_workspace(int M, int N, int K) { return dn_gemm_tn_splits(M) * (int64_t)N * K; }
-extern "C" hipError_t dn_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int M, int N, int K,
-                                 float *part, int accumulate, hipStream_t st) {
+extern "C" int64_t dn_gemm_tn_workspace(int M, int N, int K) { return dn_gemm_tn_splits(M, N, K) * (int64_t)N * K; }
+extern "C" hipError_t dn_gemm_tn_idx(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, float *C, int64_t ldc,
+                                     int M, int N, int K, float *part, int accumulate, hipStream_t st) {
     if (N <= 0 || K <= 0) return hipSuccess;
-    const int splits = (int)dn_gemm_tn_splits(M);
+    const int splits = (int)dn_gemm_tn_splits(M, N, K);
     int rows = (M + splits - 1) / splits;
     rows = (rows + 31) & ~31;
     if (rows < 32) rows = 32;
-    gemm::TnArgs a{A, lda, B, ldb, part, K, M, N, K, rows};
+    gemm::TnArgs a{A, lda, B, ldb, part, K, M, N, K, rows, bidx};
     const int blocks = ((N + 63) / 64) * ((K + 63) / 64);
     hipLaunchKernelGGL(gemm::gemm_tn_kernel, dim3(blocks, splits), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int64_t n = (int64_t)N * K;
-    hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, part, splits, N, K, C, ldc, accumulate);
+    hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, splits, N, K, C, ldc, accumulate);
     return hipGetLastError();
+}
+
+extern "C" hipError_t dn_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int M, int N, int K,
+                                 float *part, int accumulate, hipStream_t st) {
+    return dn_gemm_tn_idx(A, lda, B, ldb, nullptr, C, ldc, M, N, K, part, accumulate, st);
 }

@@ -43,16 +43,6 @@ __global__ void copy2d_kernel(int64_t M, int N, const float *__restrict__ src, i
     *d = accumulate ? *d + v : v;
 }
 
-// rows of one-hot inputs: dW[n][gidx[m]] += dP[m][n]   (dW already offset to the one-hot column block)
-__global__ void onehot_grad_kernel(int64_t M, int N, const float *__restrict__ dP, int64_t ldp, const int32_t *__restrict__ gidx,
-                                   float *__restrict__ dW, int64_t ldw) {
-    const int64_t i = gid();
-    if (i >= M * N) return;
-    const int64_t m = i / N;
-    const int n = (int)(i - m * N);
-    atomicAdd(dW + (int64_t)n * ldw + gidx[m], dP[m * ldp + n]);
-}
-
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
@@ -137,20 +127,23 @@ __global__ void gru_bwd_kernel(int64_t M, int R, const float *__restrict__ dhn, 
 // latent sample + losses (models/dagnet/model.py:118-135); per-row partial sums, reduced by sum_kernel
 // ---------------------------------------------------------------------------------------------
 // z = eps * exp(0.5 lv_e) + mu_e ;  kld_row = 0.5 * sum_z (lv_p - lv_e + (exp(lv_e) + (mu_e - mu_p)^2) / exp(lv_p) - 1)
-__global__ void vae_fwd_kernel(int64_t M, int Z, const float *__restrict__ mu_e, const float *__restrict__ lv_e,
-                               const float *__restrict__ mu_p, const float *__restrict__ lv_p, const float *__restrict__ eps,
-                               float *__restrict__ z, float *__restrict__ kld_row) {
-    const int64_t m = gid();
-    if (m >= M) return;
+// ZP (power of two >= Z, <= 64) consecutive lanes share a row: coalesced loads, shuffle reduction of the row sum
+__global__ __launch_bounds__(256) void vae_fwd_kernel(int64_t M, int Z, int ZP, const float *__restrict__ mu_e,
+                                                      const float *__restrict__ lv_e, const float *__restrict__ mu_p,
+                                                      const float *__restrict__ lv_p, const float *__restrict__ eps,
+                                                      float *__restrict__ z, float *__restrict__ kld_row) {
+    const int c = threadIdx.x % ZP;
+    const int64_t m = (int64_t)blockIdx.x * (256 / ZP) + threadIdx.x / ZP;
     float acc = 0.f;
-    for (int c = 0; c < Z; ++c) {
+    if (m < M && c < Z) {
         const int64_t i = m * Z + c;
         const float me = mu_e[i], le = lv_e[i], mp = mu_p[i], lp = lv_p[i];
         z[i] = eps[i] * expf(0.5f * le) + me;
         const float d = me - mp;
-        acc += (lp - le) + (expf(le) + d * d) / expf(lp) - 1.0f;
+        acc = (lp - le) + (expf(le) + d * d) / expf(lp) - 1.0f;
     }
-    kld_row[m] = 0.5f * acc;
+    for (int o = ZP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (m < M && c == 0) kld_row[m] = 0.5f * acc;
 }
 
 __global__ void vae_bwd_kernel(int64_t M, int Z, const float *__restrict__ mu_e, const float *__restrict__ lv_e,
@@ -263,18 +256,27 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(int64_t M, int N, int r
     }
 }
 
-// stage 2: out_q[c] (+)= scale * sum_split part[split][q][c]
-__global__ void col_finish_kernel(int N, int splits, const float *__restrict__ part, float scale, float *__restrict__ out0,
-                                  float *__restrict__ out1, int accumulate) {
-    const int c = (int)gid();
+// stage 2: out_q[c] (+)= scale * sum_split part[split][q][c]; one wave per column, lanes stride over the splits
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ __launch_bounds__(256) void col_finish_kernel(int N, int splits, const float *__restrict__ part, float scale,
+                                                         float *__restrict__ out0, float *__restrict__ out1, int accumulate) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= N) return;
     double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < splits; ++k) {
+    for (int k = lane; k < splits; k += 64) {
         s0 += (double)part[((int64_t)k * 2 + 0) * N + c];
-        s1 += (double)part[((int64_t)k * 2 + 1) * N + c];
+        if (out1) s1 += (double)part[((int64_t)k * 2 + 1) * N + c];
     }
-    if (out0) out0[c] = (accumulate ? out0[c] : 0.f) + (float)(s0 * scale);
-    if (out1) out1[c] = (accumulate ? out1[c] : 0.f) + (float)(s1 * scale);
+    s0 = wave_sum_d(s0);
+    s1 = wave_sum_d(s1);
+    if (lane == 0) {
+        if (out0) out0[c] = (accumulate ? out0[c] : 0.f) + (float)(s0 * scale);
+        if (out1) out1[c] = (accumulate ? out1[c] : 0.f) + (float)(s1 * scale);
+    }
 }
 
 // BatchNorm1d in train mode (+ optional tanh): stat = [mean | invstd]; running statistics follow nn.BatchNorm1d
@@ -540,12 +542,6 @@ extern "C" hipError_t dn_t_copy2d(int64_t M, int N, const float *src, int64_t ld
     hipLaunchKernelGGL(tops::copy2d_kernel, T_GRID(M * N), 0, st, M, N, src, lds, dst, ldd, accumulate);
     return hipGetLastError();
 }
-extern "C" hipError_t dn_t_onehot_grad(int64_t M, int N, const float *dP, int64_t ldp, const int32_t *gidx, float *dW, int64_t ldw,
-                                       hipStream_t st) {
-    if (M * N == 0) return hipSuccess;
-    hipLaunchKernelGGL(tops::onehot_grad_kernel, T_GRID(M * N), 0, st, M, N, dP, ldp, gidx, dW, ldw);
-    return hipGetLastError();
-}
 extern "C" hipError_t dn_t_softmax_fwd(int64_t M, int N, const float *X, int64_t ldx, float *Y, int64_t ldy, hipStream_t st) {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(tops::softmax_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, N, X, ldx, Y, ldy);
@@ -572,7 +568,12 @@ extern "C" hipError_t dn_t_gru_bwd(int64_t M, int R, const float *dhn, const flo
 extern "C" hipError_t dn_t_vae_fwd(int64_t M, int Z, const float *mu_e, const float *lv_e, const float *mu_p, const float *lv_p,
                                    const float *eps, float *z, float *kld_row, hipStream_t st) {
     if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(tops::vae_fwd_kernel, T_GRID(M), 0, st, M, Z, mu_e, lv_e, mu_p, lv_p, eps, z, kld_row);
+    if (Z > 64) return hipErrorInvalidValue;
+    int ZP = 1;
+    while (ZP < Z) ZP <<= 1;
+    const int rows_per_block = 256 / ZP;
+    hipLaunchKernelGGL(tops::vae_fwd_kernel, dim3((unsigned)((M + rows_per_block - 1) / rows_per_block)), dim3(256), 0, st, M, Z, ZP, mu_e,
+                       lv_e, mu_p, lv_p, eps, z, kld_row);
     return hipGetLastError();
 }
 extern "C" hipError_t dn_t_vae_bwd(int64_t M, int Z, const float *mu_e, const float *lv_e, const float *mu_p, const float *lv_p,
@@ -609,8 +610,8 @@ extern "C" hipError_t dn_t_sum(int64_t n, const float *x, float scale, float *ou
 }
 
 static int col_splits(int64_t M) {
-    int64_t s = (M + 1023) / 1024;
-    return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+    int64_t s = (M + 255) / 256;          // 256 rows per workgroup: enough workgroups to fill the chip on narrow matrices
+    return (int)(s < 1 ? 1 : (s > 512 ? 512 : s));
 }
 // floats of workspace the column reductions need for a matrix with N columns
 extern "C" int64_t dn_t_col_workspace(int64_t M, int N) { return (int64_t)col_splits(M) * 2 * N; }
@@ -623,7 +624,7 @@ static hipError_t col_reduce(int64_t M, int N, const float *X, int64_t ldx, cons
     const int rows = (int)((M + splits - 1) / splits);
     hipLaunchKernelGGL((tops::col_reduce_kernel<MODE>), dim3((N + 63) / 64, splits), dim3(256), 0, st, M, N, rows, X, ldx, stat, dOut, ldd,
                        Out, ldo, tanh_out, part);
-    hipLaunchKernelGGL(tops::col_finish_kernel, T_GRID(N), 0, st, N, splits, part, scale, out0, out1, accumulate);
+    hipLaunchKernelGGL(tops::col_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, splits, part, scale, out0, out1, accumulate);
     return hipGetLastError();
 }
 

@@ -34,8 +34,8 @@ def table_plan(scene_ptr, device) -> _capi.HipPlan:
     return plan
 
 
-def _mlp2(seq, xs, cols, gidx=None, gcol=0):
-    h = linear(seq[0], xs, cols, act=ACT_LRELU, gidx=gidx, gcol=gcol)
+def _mlp2(seq, xs, cols, gidx=None, gcol=0, gdim=0):
+    h = linear(seq[0], xs, cols, act=ACT_LRELU, gidx=gidx, gcol=gcol, gdim=gdim)
     return linear(seq[2], [h], [0], act=ACT_LRELU)
 
 
@@ -79,14 +79,14 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
         if kind == "dagnet":
             d_t = _ops.disposition(plan, traj[t], D)
             g_prev, g_t = goals[t - 1], goals[t]
-            hid = linear(model.dec_goal[0], [d_t, hl], [0, D], act=ACT_RELU, gidx=g_prev, gcol=D + R)
+            hid = linear(model.dec_goal[0], [d_t, hl], [0, D], act=ACT_RELU, gidx=g_prev, gcol=D + R, gdim=G)
             dec_g = SoftmaxFn.apply(linear(model.dec_goal[2], [hid], [0]))
             g_graph = _graph(model.graph_goals, dec_g, adj[t], plan)
             g_comb = SoftmaxFn.apply(linear(model.lg_goals[0], [dec_g, g_graph], [0, G]))
             ce = ce + CeFn.apply(g_comb, g_t)
             phi_x = _mlp2(model.phi_x, [x_t], [0])
-            enc = _mlp2(model.enc, [phi_x, hl], [0, H + G], gidx=g_t, gcol=H)
-            prior = _mlp2(model.prior, [hl], [G], gidx=g_t, gcol=0)
+            enc = _mlp2(model.enc, [phi_x, hl], [0, H + G], gidx=g_t, gcol=H, gdim=G)
+            prior = _mlp2(model.prior, [hl], [G], gidx=g_t, gcol=0, gdim=G)
         else:
             phi_x = _mlp2(model.phi_x, [x_t], [0])
             enc = _mlp2(model.enc, [phi_x, hl], [0, H])
@@ -96,7 +96,7 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
         z, k = VaeFn.apply(mu_e, lv_e, mu_p, lv_p, _eps(eps, t, N, Z, dev))
         phi_z = _mlp2(model.phi_z, [z], [0])
         if kind == "dagnet":
-            dec = _mlp2(model.dec, [d_t, phi_z, hl], [0, D + G, D + G + H], gidx=g_t, gcol=D)
+            dec = _mlp2(model.dec, [d_t, phi_z, hl], [0, D + G, D + G + H], gidx=g_t, gcol=D, gdim=G)
         else:
             dec = _mlp2(model.dec, [phi_z, hl], [0, H])
         mu_d, lv_d = linear(model.dec_mean, [dec], [0]), linear(model.dec_logvar, [dec], [0])
@@ -134,6 +134,43 @@ def train_step(model, optimizer: "_ops.ClipAdam", batch, kld_weight=1.0, ce_weig
     loss.backward()
     optimizer.step()
     return dict(loss=loss.detach(), kld=kld.detach(), nll=nll.detach(), ce=ce.detach())
+
+
+class GraphedForwardBackward:
+    """Forward + backward of one training step captured once in a hipGraph (torch.cuda.CUDAGraph) and replayed: the
+    layer-by-layer step is ~20 000 small launches, which the host cannot issue as fast as the GPU retires them.
+    The batch shape (scene layout, sequence length) is fixed at capture; new data is copied into the static inputs.
+    The gradient all-reduce and the optimizer step stay outside the graph.
+
+        gfb = GraphedForwardBackward(model, loss_fn, example_inputs)     # loss_fn(model, *inputs) -> (loss, aux tuple)
+        loss, aux = gfb(*inputs); optimizer.step()
+    """
+
+    def __init__(self, model, loss_fn, inputs, warmup=2):
+        self.model, self.loss_fn = model, loss_fn
+        self.static = [t.clone() if torch.is_tensor(t) else t for t in inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):              # plans, scratch buffers and the allocator reach their steady state
+                for p in model.parameters():
+                    p.grad = None
+                loss, _ = loss_fn(model, *self.static)
+                loss.backward()
+        torch.cuda.current_stream().wait_stream(side)
+        for p in model.parameters():
+            p.grad = None
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.aux = loss_fn(model, *self.static)
+            self.loss.backward()
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static, inputs):
+            if torch.is_tensor(dst) and src is not dst:
+                dst.copy_(src)
+        self.graph.replay()
+        return self.loss, self.aux
 
 
 def allreduce_gradients(params, world_size=None):

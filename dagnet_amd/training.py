@@ -111,11 +111,14 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
     return kld, nll, ce, torch.stack(h, 0)
 
 
-def train_step(model, optimizer: "_ops.ClipAdam", batch, kld_weight=1.0, ce_weight=1.0, eps=None):
+def train_step(model, optimizer: "_ops.ClipAdam", batch, kld_weight=1.0, ce_weight=1.0, eps=None, row_fraction=1.0):
     """The reference's training step (train_bsk.py:259-291): zero_grad, train-mode forward, loss = kld_weight KLD + NLL
     (+ ce_weight CE), backward, clip_grad_norm_ + Adam (both inside ``optimizer.step()``).
 
     batch: VRNN (x_rel,) | A-VRNN (x_rel, adj[, seq_start_end]) | DAG-Net (traj, traj_rel, goals_ohe, seq_start_end, adj).
+    Data parallel (scenes sharded over ranks): KLD and NLL are means over the rows, CE is a sum, so a rank holding
+    ``row_fraction`` = N_local / N_global of the rows scales its KLD/NLL terms by that fraction; the all-reduced (summed)
+    gradients then equal the single-process gradients (up to per-shard BatchNorm statistics).
     -> dict(loss, kld, nll, ce) of [1] device tensors (no host synchronisation)."""
     model.train()
     optimizer.zero_grad()
@@ -123,15 +126,16 @@ def train_step(model, optimizer: "_ops.ClipAdam", batch, kld_weight=1.0, ce_weig
     if name == "VRNN":
         kld, nll, _ = model(batch[0], eps=eps)
         ce = torch.zeros_like(kld)
-        loss = kld_weight * kld + nll
+        loss = row_fraction * (kld_weight * kld + nll)
     elif name == "AVRNN":
         kld, nll, _ = model(batch[0], batch[1], seq_start_end=batch[2] if len(batch) > 2 else None, eps=eps)
         ce = torch.zeros_like(kld)
-        loss = kld_weight * kld + nll
+        loss = row_fraction * (kld_weight * kld + nll)
     else:
         kld, nll, ce, _ = model(*batch, eps=eps)
-        loss = kld_weight * kld + nll + ce_weight * ce
+        loss = row_fraction * (kld_weight * kld + nll) + ce_weight * ce
     loss.backward()
+    allreduce_gradients(optimizer.params)
     optimizer.step()
     return dict(loss=loss.detach(), kld=kld.detach(), nll=nll.detach(), ce=ce.detach())
 

@@ -69,3 +69,61 @@ def test_sharded_evaluation_equals_single_process():
     tot = _shard_sums(batch, sd, cfg, a, 0, sum(SIZES))
     want = (float(tot[0] / (tot[2] * T_PRED)), float(tot[1] / tot[2]))
     assert abs(got[0] - want[0]) < 1e-9 * max(1, abs(want[0])) + 1e-6 and abs(got[1] - want[1]) < 1e-6
+
+
+# ---- data-parallel training step (row T): one flat all-reduce of the gradients ----------------------
+def _vrnn_grads(x_rel, eps, sd, cfg, weight):
+    """Oracle gradients of weight * (KLD + NLL) on a shard (the HIP operators need a GPU; this test covers the reduction)."""
+    params = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    kld, nll, _ = orc.vrnn_forward(params, cfg, x_rel, eps)
+    grads = torch.autograd.grad((weight * (kld + nll)).sum(), list(params.values()), allow_unused=True)
+    return {k: (g if g is not None else torch.zeros_like(params[k])) for k, g in zip(params, grads)}
+
+
+def _train_setup():
+    import dagnet_amd
+    a = syn.make_args(h_dim=16, z_dim=8, rnn_dim=16, n_layers=2, pred_len=T_PRED, obs_len=T_OBS)
+    model = dagnet_amd.VRNN(a)
+    sd = syn.random_state_dict(model, SEED)
+    model.load_state_dict(sd)
+    cfg = orc.make_cfg(h_dim=16, z_dim=8, rnn_dim=16, n_layers=2)
+    batch = syn.make_batch(SIZES, T_OBS, T_PRED, SEED)
+    eps = syn.uniform_noise(SEED, "eps_train", (T_OBS - 1, sum(SIZES), a.z_dim))
+    return model, sd, cfg, batch, eps
+
+
+def _train_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dagnet_amd.training import allreduce_gradients
+    model, sd, cfg, batch, eps = _train_setup()
+    local, local_sizes = shard_batch(batch, SIZES, world, rank)
+    row0 = int(sum(SIZES[: shard_scenes(SIZES, world, rank)[0]]))
+    n_local = int(sum(local_sizes))
+    g = _vrnn_grads(local[2], eps[:, row0:row0 + n_local], sd, cfg, n_local / sum(SIZES))
+    for k, p in model.named_parameters():
+        p.grad = g[k].clone()
+    allreduce_gradients(list(model.parameters()))
+    if rank == 0:
+        out.put({k: p.grad.numpy() for k, p in model.named_parameters()})
+    dist.destroy_process_group()
+
+
+def test_sharded_training_gradients_equal_single_process():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    model, sd, cfg, batch, eps = _train_setup()
+    want = _vrnn_grads(batch[2], eps, sd, cfg, 1.0)
+    for k, w in want.items():
+        np.testing.assert_allclose(got[k], w.numpy(), rtol=2e-4, atol=2e-6, err_msg=k)

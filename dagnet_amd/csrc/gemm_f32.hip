@@ -44,9 +44,10 @@ __device__ __forceinline__ float act_apply(int act, float v, float slope) {
 }
 
 // Wave grid WM x WN (WM*WN == 4), per-wave TM x TN tiles of 32x32.  Tile of the workgroup: (WM*TM*32) x (WN*TN*32).
-// VEC: float4 staging loads (needs 16-byte aligned operands, lda/ldw/K multiples of 4); else scalar loads.
+// VECA / VECB: float4 staging loads of that operand (needs a 16-byte aligned base, a row stride and an extent along the
+// load direction that are multiples of 4); else scalar loads.
 // TRANSB: the second operand is B[K, N] row-major (ldw = its row stride) instead of W[N, K].
-template <int WM, int WN, int TM, int TN, bool VEC, bool TRANSB>
+template <int WM, int WN, int TM, int TN, bool VECA, bool VECB, bool TRANSB>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int LA = BM * 8 / 256, LB = BN * 8 / 256;      // float4 loads per thread and chunk
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;          // this thread's (row, k) inside a 32-row slab of a chunk
     f32x4 ga[LA], gb[LB];
     // 4 consecutive elements of row r starting at column c of a [nr, nc] matrix, zero outside
-    auto ld4 = [&](const float *base, int64_t ld, int r, int nr, int c, int nc) {
+    auto ld4 = [&](const float *base, int64_t ld, int r, int nr, int c, int nc, bool VEC) {
         f32x4 v = {0, 0, 0, 0};
         if (r < nr) {
             const float *q = base + (int64_t)r * ld + c;
@@ -84,14 +85,14 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
     constexpr int BN4 = BN / 4;
     auto gload = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < LA; ++i) ga[i] = ld4(p.A, p.lda, m0 + lrow + 32 * i, p.M, k0 + lc4, p.K);
+        for (int i = 0; i < LA; ++i) ga[i] = ld4(p.A, p.lda, m0 + lrow + 32 * i, p.M, k0 + lc4, p.K, VECA);
 #pragma unroll
         for (int i = 0; i < LB; ++i) {
             if (TRANSB) {      // element e of the [32 k][BN n] slab: 4 consecutive n of one k
                 const int e = tid + 256 * i, kr = e / BN4, c4 = (e % BN4) * 4;
-                gb[i] = ld4(p.W, p.ldw, k0 + kr, p.K, n0 + c4, p.N);
+                gb[i] = ld4(p.W, p.ldw, k0 + kr, p.K, n0 + c4, p.N, VECB);
             } else {
-                gb[i] = ld4(p.W, p.ldw, n0 + lrow + 32 * i, p.N, k0 + lc4, p.K);
+                gb[i] = ld4(p.W, p.ldw, n0 + lrow + 32 * i, p.N, k0 + lc4, p.K, VECB);
             }
         }
     };
@@ -273,35 +274,41 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float *part, i
 }
 
 template <int WM, int WN, int TM, int TN>
-static hipError_t launch_nt_cfg(const NtArgs &a, bool vec, bool transb, hipStream_t st) {
+static hipError_t launch_nt_cfg(const NtArgs &a, bool veca, bool vecb, bool transb, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
     const int64_t blocks = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     if (blocks <= 0) return hipSuccess;
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 g((unsigned)blocks), t(256);
-    if (vec && !transb) hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, false>), g, t, lds, st, a);
-    else if (vec) hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, true, true>), g, t, lds, st, a);
-    else if (!transb) hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false, false>), g, t, lds, st, a);
-    else hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, false, true>), g, t, lds, st, a);
-    return hipGetLastError();
+#define DN_NT_CASE(VA, VB, TB)                                                                                        \
+    if (veca == VA && vecb == VB && transb == TB) {                                                                   \
+        hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, VA, VB, TB>), g, t, lds, st, a);                           \
+        return hipGetLastError();                                                                                     \
+    }
+    DN_NT_CASE(true, true, false) DN_NT_CASE(true, true, true) DN_NT_CASE(true, false, false) DN_NT_CASE(true, false, true)
+    DN_NT_CASE(false, true, false) DN_NT_CASE(false, true, true) DN_NT_CASE(false, false, false) DN_NT_CASE(false, false, true)
+#undef DN_NT_CASE
+    return hipErrorInvalidValue;
 }
 
 }  // namespace gemm
 
 // General entry: C = act([C +] A op(B) + bias + gather), op(B) = W[N,K]^T (transb = 0) or B[K,N] (transb = 1).
-// Aligned operands with strides and K (transb: N) multiples of 4 take float4 staging loads, anything else scalar loads.
+// An operand that is 16-byte aligned with a row stride and a load-direction extent that are multiples of 4 takes float4
+// staging loads, anything else scalar loads.  Tiles: 128x128 for wide outputs, 128x64 / 128x32 (2 workgroups per CU) for
+// the narrow layers, which are bound by streaming A and C rather than by the MFMAs.
 extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
                               int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
                               const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
     if (act < gemm::ACT_NONE || act > gemm::ACT_RELU) return hipErrorInvalidValue;
-    const bool vec = !((lda & 3) || (ldb & 3) || (K & 3) || (transb && (N & 3)) || (reinterpret_cast<uintptr_t>(A) & 15) ||
-                       (reinterpret_cast<uintptr_t>(B) & 15));
+    const bool veca = !((lda & 3) || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15));
+    const bool vecb = !((ldb & 3) || ((transb ? N : K) & 3) || (reinterpret_cast<uintptr_t>(B) & 15));
     gemm::NtArgs a{A, lda, B, ldb, bias, C, ldc, M, N, K, slope, gather, gidx, gs_g, gs_n, act, accumulate};
-    if (N > 64) return gemm::launch_nt_cfg<2, 2, 2, 2>(a, vec, transb != 0, st);     // 128 x 128
-    if (N > 32) return gemm::launch_nt_cfg<4, 1, 2, 2>(a, vec, transb != 0, st);     // 256 x 64
-    return gemm::launch_nt_cfg<4, 1, 2, 1>(a, vec, transb != 0, st);                 // 256 x 32
+    if (N > 64) return gemm::launch_nt_cfg<2, 2, 2, 2>(a, veca, vecb, transb != 0, st);     // 128 x 128
+    if (N > 32) return gemm::launch_nt_cfg<2, 2, 2, 1>(a, veca, vecb, transb != 0, st);     // 128 x 64
+    return gemm::launch_nt_cfg<4, 1, 1, 1>(a, veca, vecb, transb != 0, st);                 // 128 x 32
 }
 
 extern "C" hipError_t dn_gemm_nt_gather(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *C,
@@ -320,7 +327,7 @@ extern "C" hipError_t dn_gemm_nt(const float *A, int64_t lda, const float *W, in
 // splits over the rows: enough workgroups to fill 256 CUs twice, at least 256 rows each
 extern "C" int64_t dn_gemm_tn_splits(int M, int N, int K) {
     const int64_t blocks = (int64_t)((N + 63) / 64) * ((K + 63) / 64);
-    int64_t s = (384 + blocks - 1) / blocks;
+    int64_t s = (768 + blocks - 1) / blocks;
     const int64_t cap = (M + 255) / 256;
     if (s > cap) s = cap;
     return s < 1 ? 1 : (s > 512 ? 512 : s);

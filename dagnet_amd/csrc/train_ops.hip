@@ -334,7 +334,38 @@ struct Scenes {
 
 // GAT attention of one layer (gat_layers.py:25-40) for H heads of width F stacked along the columns of Wh:
 //   s1_i = Wh_i . a[:F], s2_j = Wh_j . a[F:], e_ij = leakyrelu(s1_i + s2_j) where adj_ij > 0, att = softmax_j, out = att Wh (elu)
-// grid (S, H); dynamic LDS: Wh [n][F] | s1 [n] | s2 [n] | att [n][n]
+// grid (S, H); dynamic LDS: Wh [n][F] | s1 [n] | s2 [n] | att [n][n].  Pair (i,j) and (row, feature) loops are spread over
+// the 128 threads; only the O(n) row normalisations run on n threads.
+__device__ __forceinline__ void gat_logits(int n, int F, int64_t rld, const float *wh, const float *ah, const float *ablk, float alpha,
+                                           float *s1, float *s2, float *att, int tid) {
+    for (int e = tid; e < 2 * n; e += 128) {
+        const int i = e >> 1, w = e & 1;
+        float u = 0.f;
+        for (int f = 0; f < F; ++f) u += wh[i * F + f] * ah[w * F + f];
+        (w ? s2 : s1)[i] = u;
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += 128) {
+        const int i = e / n, j = e - i * n;
+        const float v = s1[i] + s2[j];
+        att[e] = ablk[i * rld + j] > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 128) {
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j) mx = fmaxf(mx, att[i * n + j]);
+        float sum = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float w = att[i * n + j] == -INFINITY ? 0.f : expf(att[i * n + j] - mx);
+            att[i * n + j] = w;
+            sum += w;
+        }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < n; ++j) att[i * n + j] *= inv;
+    }
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(128) void gat_attn_fwd_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
                                                           int64_t ldw, const float *__restrict__ a, int F, float alpha, int elu,
                                                           float *__restrict__ Out, int64_t ldo) {
@@ -348,27 +379,7 @@ __global__ __launch_bounds__(128) void gat_attn_fwd_kernel(Scenes sc, const floa
     const int tid = threadIdx.x;
     for (int e = tid; e < n * F; e += 128) wh[e] = Wh[(int64_t)(b + e / F) * ldw + hd * F + e % F];
     __syncthreads();
-    for (int i = tid; i < n; i += 128) {
-        float u = 0.f, v = 0.f;
-        for (int f = 0; f < F; ++f) { u += wh[i * F + f] * ah[f]; v += wh[i * F + f] * ah[F + f]; }
-        s1[i] = u; s2[i] = v;
-    }
-    __syncthreads();
-    for (int i = tid; i < n; i += 128) {
-        float mx = -INFINITY;
-        for (int j = 0; j < n; ++j)
-            if (ablk[i * rld + j] > 0.f) { const float e = s1[i] + s2[j]; mx = fmaxf(mx, fmaxf(e, e * alpha)); }
-        float sum = 0.f;
-        for (int j = 0; j < n; ++j) {
-            float w = 0.f;
-            if (ablk[i * rld + j] > 0.f) { const float e = s1[i] + s2[j]; w = expf(fmaxf(e, e * alpha) - mx); }
-            att[i * n + j] = w;
-            sum += w;
-        }
-        const float inv = 1.0f / sum;
-        for (int j = 0; j < n; ++j) att[i * n + j] *= inv;
-    }
-    __syncthreads();
+    gat_logits(n, F, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
     for (int e = tid; e < n * F; e += 128) {
         const int i = e / F, f = e % F;
         float acc = 0.f;
@@ -378,7 +389,7 @@ __global__ __launch_bounds__(128) void gat_attn_fwd_kernel(Scenes sc, const floa
     }
 }
 
-// backward of the above.  dynamic LDS: Wh [n][F] | dO [n][F] | dWh [n][F] | s1 | s2 | ds1 | ds2 [n] each | att [n][n] | dpre [n][n]
+// backward of the above.  dynamic LDS: Wh [n][F] | dO [n][F] | s1 | s2 | ds1 | ds2 | dot [n] each | att [n][n] | dpre [n][n]
 // da (H x 2F) is accumulated with atomics over the scenes.
 __global__ __launch_bounds__(128) void gat_attn_bwd_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
                                                           int64_t ldw, const float *__restrict__ a, int F, float alpha, int elu,
@@ -387,8 +398,8 @@ __global__ __launch_bounds__(128) void gat_attn_bwd_kernel(Scenes sc, const floa
     extern __shared__ float sm[];
     const int s = blockIdx.x, hd = blockIdx.y;
     const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b;
-    float *wh = sm, *dO = wh + n * F, *dw = dO + n * F, *s1 = dw + n * F, *s2 = s1 + n, *ds1 = s2 + n, *ds2 = ds1 + n;
-    float *att = ds2 + n, *dpre = att + n * n;
+    float *wh = sm, *dO = wh + n * F, *s1 = dO + n * F, *s2 = s1 + n, *ds1 = s2 + n, *ds2 = ds1 + n, *dot = ds2 + n;
+    float *att = dot + n, *dpre = att + n * n;
     const float *ah = a + (int64_t)hd * 2 * F;
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
@@ -402,47 +413,33 @@ __global__ __launch_bounds__(128) void gat_attn_bwd_kernel(Scenes sc, const floa
         dO[e] = g;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 128) {
-        float u = 0.f, v = 0.f;
-        for (int f = 0; f < F; ++f) { u += wh[i * F + f] * ah[f]; v += wh[i * F + f] * ah[F + f]; }
-        s1[i] = u; s2[i] = v;
+    gat_logits(n, F, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
+    // d att_ij = dO_i . Wh_j
+    for (int e = tid; e < n * n; e += 128) {
+        const int i = e / n, j = e - i * n;
+        float d = 0.f;
+        for (int f = 0; f < F; ++f) d += dO[i * F + f] * wh[j * F + f];
+        dpre[e] = d;
     }
     __syncthreads();
     for (int i = tid; i < n; i += 128) {
-        float mx = -INFINITY;
-        for (int j = 0; j < n; ++j)
-            if (ablk[i * rld + j] > 0.f) { const float e = s1[i] + s2[j]; mx = fmaxf(mx, fmaxf(e, e * alpha)); }
-        float sum = 0.f;
-        for (int j = 0; j < n; ++j) {
-            float w = 0.f;
-            if (ablk[i * rld + j] > 0.f) { const float e = s1[i] + s2[j]; w = expf(fmaxf(e, e * alpha) - mx); }
-            att[i * n + j] = w;
-            sum += w;
-        }
-        const float inv = 1.0f / sum;
-        // d att_ij = dO_i . Wh_j ;  d e_ij = att_ij (d att_ij - sum_k att_ik d att_ik) ;  through the leaky relu
-        float dot = 0.f;
-        for (int j = 0; j < n; ++j) {
-            att[i * n + j] *= inv;
-            float d = 0.f;
-            for (int f = 0; f < F; ++f) d += dO[i * F + f] * wh[j * F + f];
-            dpre[i * n + j] = d;
-            dot += att[i * n + j] * d;
-        }
         float acc = 0.f;
-        for (int j = 0; j < n; ++j) {
-            const float e = s1[i] + s2[j];
-            const float de = att[i * n + j] * (dpre[i * n + j] - dot) * (e > 0.f ? 1.f : alpha);
-            dpre[i * n + j] = de;
-            acc += de;
-        }
-        ds1[i] = acc;
+        for (int j = 0; j < n; ++j) acc += att[i * n + j] * dpre[i * n + j];
+        dot[i] = acc;
     }
     __syncthreads();
-    for (int j = tid; j < n; j += 128) {
+    // d e_ij = att_ij (d att_ij - sum_k att_ik d att_ik), through the leaky relu
+    for (int e = tid; e < n * n; e += 128) {
+        const int i = e / n, j = e - i * n;
+        const float v = s1[i] + s2[j];
+        dpre[e] = att[e] * (dpre[e] - dot[i]) * (v > 0.f ? 1.f : alpha);
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * n; e += 128) {
+        const int i = e >> 1;
         float acc = 0.f;
-        for (int i = 0; i < n; ++i) acc += dpre[i * n + j];
-        ds2[j] = acc;
+        if (e & 1) { for (int k = 0; k < n; ++k) acc += dpre[k * n + i]; ds2[i] = acc; }
+        else       { for (int k = 0; k < n; ++k) acc += dpre[i * n + k]; ds1[i] = acc; }
     }
     __syncthreads();
     for (int e = tid; e < n * F; e += 128) {
@@ -664,7 +661,7 @@ extern "C" hipError_t dn_t_bn_bwd(int64_t M, int N, const float *X, int64_t ldx,
 
 extern "C" int64_t dn_t_gat_lds_bytes(int n_max, int F, int backward) {
     const int64_t n = n_max;
-    return sizeof(float) * (backward ? 3 * n * F + 4 * n + 2 * n * n : n * F + 2 * n + n * n);
+    return sizeof(float) * (backward ? 2 * n * F + 5 * n + 2 * n * n : n * F + 2 * n + n * n);
 }
 extern "C" hipError_t dn_t_gat_attn_fwd(const int32_t *scene_ptr, const int64_t *off_compact, int S, int n_max, int64_t adj_ld, const float *adj,
                                         const float *Wh, int64_t ldw, const float *a, int H, int F, float alpha, int elu, float *Out,

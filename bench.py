@@ -163,7 +163,7 @@ def bench_train(opt, wl, rank, world, dev, dist):
     from dagnet_amd.adjacency_matrix import BlockDiagAdj
     adj = compute_adjs_distsim(a, sse, obs, gt, compact=True)
     optim = _ops.ClipAdam(list(model.parameters()), lr=1e-3, clip=10.0)
-    params = list(model.parameters())
+    training.attach_grad_arena(model, optim)
 
     frac = 1.0 / world                          # KLD / NLL are means over the rows of the shard, CE is a sum
     eps_all = torch.empty((T - 1, n_rows, a.z_dim), dtype=torch.float32, device=dev)
@@ -182,7 +182,7 @@ def bench_train(opt, wl, rank, world, dev, dist):
             optim.zero_grad()
             loss, _ = loss_fn(model, eps_all)
             loss.backward()
-        training.allreduce_gradients(params)
+        training.allreduce_gradients(optim)
         optim.step()
         return loss
 

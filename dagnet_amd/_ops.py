@@ -41,7 +41,7 @@ def _lib():
         lib.dagnet_op_gemm_tn.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, vp]
         lib.dagnet_op_act_bwd.argtypes = [i64, i32, vp, i64, vp, i64, vp, i64, i32, f32, vp]
         lib.dagnet_op_copy2d.argtypes = [i64, i32, vp, i64, vp, i64, i32, vp]
-        lib.dagnet_op_onehot_grad.argtypes = [i64, i32, i32, vp, i64, vp, vp, i64, vp, vp]
+        lib.dagnet_op_onehot_grad.argtypes = [i64, i32, i32, vp, i64, vp, vp, i64, vp, i32, vp]
         lib.dagnet_op_softmax_fwd.argtypes = [i64, i32, vp, i64, vp, i64, vp]
         lib.dagnet_op_softmax_bwd.argtypes = [i64, i32, vp, i64, vp, i64, vp, i64, vp]
         lib.dagnet_op_gru_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp]
@@ -143,6 +143,17 @@ def copy2d(src, dst, accumulate=False):
     _check(_lib().dagnet_op_copy2d(src.shape[0], src.shape[1], s, lds, d, ldd, int(accumulate), _stream(src.device)))
 
 
+def _sink(p: torch.Tensor):
+    """Gradient arena view of a parameter (training.attach_grad_arena): the backward kernels then accumulate straight into
+    p.grad and hand autograd None, which saves one zero-fill and one torch add per parameter use and time step."""
+    if p is None or not p.is_leaf or not getattr(p, "_hip_sink", False):
+        return None
+    g = p.grad
+    if g is not None and getattr(p, "_hip_sink", False) and g.is_contiguous() and g.dtype == torch.float32 and g.shape == p.shape:
+        return g
+    return None
+
+
 def _empty(M, N, like):
     return torch.empty((M, N), dtype=torch.float32, device=like.device)
 
@@ -170,6 +181,7 @@ class LinearFn(torch.autograd.Function):
             else:
                 gemm(x, Wp, y, bias=b if fin else None, act=act if fin else ACT_NONE, slope=slope, accumulate=s > 0)
         ctx.save_for_backward(W, y, gidx, *xs)
+        ctx.W_param, ctx.b_param = W, b          # the leaf parameters themselves (for their gradient sinks)
         ctx.meta = (act, slope, tuple(cols), gcol, gdim, b is not None)
         return y
 
@@ -188,17 +200,25 @@ class LinearFn(torch.autograd.Function):
             dpre = dy
         dW = db = None
         if ctx.needs_input_grad[0]:
-            dW = torch.zeros_like(W)
+            sink = _sink(ctx.W_param)
+            dW = sink if sink is not None else torch.zeros_like(W)
+            acc = sink is not None
             for x, c0 in zip(xs, cols):
-                gemm_tn(dpre, x, dW[:, c0:c0 + x.shape[1]])
+                gemm_tn(dpre, x, dW[:, c0:c0 + x.shape[1]], accumulate=acc)
             if gidx is not None:
                 (dp, ldp) = _m(dpre)
                 ws = _ws(y.device, _lib().dagnet_op_gemm_tn_workspace(M, N, gdim))
                 _check(_lib().dagnet_op_onehot_grad(M, N, gdim, dp, ldp, _p(gidx), C.c_void_p(dW.data_ptr() + 4 * gcol), Ktot, _p(ws),
-                                                    _stream(y.device)))
+                                                    int(acc), _stream(y.device)))
+            if acc:
+                dW = None
         if has_b and ctx.needs_input_grad[1]:
-            db = torch.empty(N, dtype=torch.float32, device=y.device)
-            colsum(dpre, db)
+            sink = _sink(ctx.b_param)
+            if sink is not None:
+                colsum(dpre, sink, accumulate=True)
+            else:
+                db = torch.empty(N, dtype=torch.float32, device=y.device)
+                colsum(dpre, db)
         dxs = []
         for i, (x, c0) in enumerate(zip(xs, cols)):
             if ctx.needs_input_grad[8 + i]:
@@ -224,6 +244,7 @@ class MatmulFn(torch.autograd.Function):
         y = _empty(x.shape[0], W.shape[1], x)
         gemm(x, W, y, transb=True)
         ctx.save_for_backward(x, W)
+        ctx.W_param = W
         return y
 
     @staticmethod
@@ -235,8 +256,12 @@ class MatmulFn(torch.autograd.Function):
             dx = _empty(x.shape[0], x.shape[1], x)
             gemm(dy, W, dx)                       # dy [M,N] . W[K,N]^T
         if ctx.needs_input_grad[1]:
-            dW = torch.empty_like(W)
-            gemm_tn(x, dy, dW)
+            sink = _sink(ctx.W_param)
+            if sink is not None:
+                gemm_tn(x, dy, sink, accumulate=True)
+            else:
+                dW = torch.empty_like(W)
+                gemm_tn(x, dy, dW)
         return dx, dW
 
 
@@ -542,6 +567,10 @@ class ClipAdam:
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
 
     def zero_grad(self):
+        arena = getattr(self, "arena", None)
+        if arena is not None and all(getattr(p, "_hip_sink", False) and p.grad is not None for p in self.params):
+            arena.zero_()                       # the parameters' .grad are views of one flat buffer
+            return
         for p in self.params:
             p.grad = None
 
@@ -552,10 +581,14 @@ class ClipAdam:
             return
         st = _stream(live[0][0].device)
         self.sumsq.zero_()
-        for p, _, _ in live:
-            if not p.grad.is_contiguous():
-                p.grad = p.grad.contiguous()
-            _check(lib.dagnet_op_sumsq(p.grad.numel(), _p(p.grad), _p(self.sumsq), st))
+        arena = getattr(self, "arena", None)
+        if arena is not None and len(live) == len(self.params):
+            _check(lib.dagnet_op_sumsq(arena.numel(), _p(arena), _p(self.sumsq), st))      # all gradients are one flat buffer
+        else:
+            for p, _, _ in live:
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+                _check(lib.dagnet_op_sumsq(p.grad.numel(), _p(p.grad), _p(self.sumsq), st))
         self.step_count += 1
         for p, m, v in live:
             _check(lib.dagnet_op_adam(p.numel(), _p(p.data), _p(p.grad), _p(m), _p(v), _p(self.sumsq), float(self.clip or 0.0), self.lr,

@@ -1315,11 +1315,11 @@ extern "C" int dagnet_op_copy2d(int64_t M, int32_t N, const float *src, int64_t 
     return DAGNET_OK;
 }
 extern "C" int dagnet_op_onehot_grad(int64_t M, int32_t N, int32_t G, const float *dP, int64_t ldp, const int32_t *gidx, float *dW,
-                                     int64_t ldw, float *workspace, void *stream) {
+                                     int64_t ldw, float *workspace, int32_t accumulate, void *stream) {
     OP_NEED(M >= 0 && N >= 0 && G >= 0 && M <= 0x7fffffffLL && (M * N == 0 || (dP && gidx && dW && workspace)), "bad argument");
     if (M * N == 0 || G == 0) return DAGNET_OK;
     // dW[n][g] = sum_m dP[m][n] * onehot(gidx[m])[g]: the weight-gradient GEMM with a generated one-hot operand
-    HIP_TRY(dn_gemm_tn_idx(dP, ldp, nullptr, 0, gidx, dW, ldw, (int)M, N, G, workspace, 0, OP_ST));
+    HIP_TRY(dn_gemm_tn_idx(dP, ldp, nullptr, 0, gidx, dW, ldw, (int)M, N, G, workspace, accumulate, OP_ST));
     return DAGNET_OK;
 }
 extern "C" int dagnet_op_softmax_fwd(int64_t M, int32_t N, const float *X, int64_t ldx, float *Y, int64_t ldy, void *stream) {

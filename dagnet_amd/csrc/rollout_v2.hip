@@ -367,9 +367,18 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     const V2Weights &W = *Wp;     // offsets are fetched with scalar loads where they are used (no SGPR residency)
     __shared__ float xch[32 * 4 + 64];
     // DAG-Net: hidden state parked in LDS while the goal head needs the registers ([tile][reg][lane], conflict free)
-    __shared__ float stash[MODEL == 2 ? NL * 32 * 64 : 1];
+    // also (NL == 2): the top layer's state is parked while GRU layer 0 runs (its 4 input tiles + 2 state tiles + gate
+    // temporaries do not fit beside it; the compiler would spill ~140 registers to scratch memory instead)
+    __shared__ float stash[MODEL == 2 ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
     float *pos = xch + 128;                 // [32][2] current absolute positions of the tile rows
     const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
+#ifdef DN_V2_STAGGER
+    {   // de-synchronise the two waves of a SIMD: identical programs started together stay in lockstep and then want the
+        // MFMA pipe, and later the VALU, at the same time; a pseudo-random start delay of up to ~one step breaks that
+        const unsigned d = (blockIdx.x * 2654435761u >> 20) % DN_V2_STAGGER;
+        for (unsigned i = 0; i < d; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     WBuf wp;
     wp.init(R.wp);
     constexpr bool DAG = MODEL >= 2, GRAPH = MODEL != 0, HEAD = MODEL == 2, EXT = MODEL == 3;
@@ -690,8 +699,20 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
                 for (int r = 0; r < 16; ++r) h[0][nt][r] = stash[((2 + nt) * 16 + r) * 64 + lane];
         }
         const int after_gru = GRAPH ? W.g_hid.heads : first_off;
+        if constexpr (NL == 2) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stash[(nt * 16 + r) * 64 + lane] = h[1][nt][r];
+        }
         pre = gru<4>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? W.gru[1].nh.w[0] : after_gru);
-        if constexpr (NL == 2) pre = gru<2>(h[0], h[1], wp, W.gru[1], lane, pre, after_gru);
+        if constexpr (NL == 2) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[1][nt][r] = stash[(nt * 16 + r) * 64 + lane];
+            pre = gru<2>(h[0], h[1], wp, W.gru[1], lane, pre, after_gru);
+        }
         PH(8);
         // -------------------------------------------------------------------- graph refinement of h[-1]
         if (MODEL == 1) {       // A-VRNN: adjacency from the UPDATED positions (models/avrnn/model.py:201-209)

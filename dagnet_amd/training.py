@@ -34,6 +34,26 @@ def table_plan(scene_ptr, device) -> _capi.HipPlan:
     return plan
 
 
+def attach_grad_arena(model, optimizer=None) -> torch.Tensor:
+    """Give every parameter's .grad a view of ONE flat fp32 buffer (zeroed) and mark the parameters as gradient sinks: the
+    weight / bias gradient kernels of _ops then accumulate in place over the time steps instead of returning fresh tensors
+    for autograd to add up, and the data-parallel all-reduce is one call on the flat buffer.  Plain autograd semantics
+    otherwise (gradients accumulate over backward() calls until zeroed); torch.autograd.grad(loss, params) is not
+    supported for sink parameters (they report None)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    arena = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad = arena[off:off + n].view_as(p)
+        p._hip_sink = True
+        off += n
+    model._hip_grad_arena = arena
+    if optimizer is not None:
+        optimizer.arena = arena
+    return arena
+
+
 def _mlp2(seq, xs, cols, gidx=None, gcol=0, gdim=0):
     h = linear(seq[0], xs, cols, act=ACT_LRELU, gidx=gidx, gcol=gcol, gdim=gdim)
     return linear(seq[2], [h], [0], act=ACT_LRELU)
@@ -135,7 +155,7 @@ def train_step(model, optimizer: "_ops.ClipAdam", batch, kld_weight=1.0, ce_weig
         kld, nll, ce, _ = model(*batch, eps=eps)
         loss = row_fraction * (kld_weight * kld + nll) + ce_weight * ce
     loss.backward()
-    allreduce_gradients(optimizer.params)
+    allreduce_gradients(optimizer if getattr(optimizer, "arena", None) is not None else optimizer.params)
     optimizer.step()
     return dict(loss=loss.detach(), kld=kld.detach(), nll=nll.detach(), ce=ce.detach())
 
@@ -155,17 +175,26 @@ class GraphedForwardBackward:
         self.static = [t.clone() if torch.is_tensor(t) else t for t in inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):              # plans, scratch buffers and the allocator reach their steady state
+        arena = getattr(model, "_hip_grad_arena", None)
+
+        def zero():
+            if arena is not None:
+                arena.zero_()                    # flat gradient buffer (attach_grad_arena): one memset, captured with the step
+            else:
                 for p in model.parameters():
                     p.grad = None
+        with torch.cuda.stream(side):
+            for _ in range(warmup):              # plans, scratch buffers and the allocator reach their steady state
+                zero()
                 loss, _ = loss_fn(model, *self.static)
                 loss.backward()
         torch.cuda.current_stream().wait_stream(side)
-        for p in model.parameters():
-            p.grad = None
+        if arena is None:
+            zero()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
+            if arena is not None:
+                zero()
             self.loss, self.aux = loss_fn(model, *self.static)
             self.loss.backward()
 
@@ -178,12 +207,17 @@ class GraphedForwardBackward:
 
 
 def allreduce_gradients(params, world_size=None):
-    """Data-parallel training: one flat all-reduce(SUM) of every gradient over the ranks (RCCL over xGMI),
+    """``params``: a parameter list, or an optimizer whose gradients live in one flat arena (attach_grad_arena).
+    Data-parallel training: one flat all-reduce(SUM) of every gradient over the ranks (RCCL over xGMI),
     between backward() and the optimizer step.  Scenes are sharded, weights replicated; the losses are sums over rows,
     so gradients add up (no averaging), exactly as one rank seeing the whole batch -- except BatchNorm, whose batch
     statistics stay per shard (documented deviation)."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized() or (world_size or dist.get_world_size()) == 1:
+        return
+    arena = getattr(params, "arena", None)
+    if arena is not None:                      # attach_grad_arena: the gradients already are one flat buffer
+        dist.all_reduce(arena)
         return
     grads = [p.grad for p in params if p.grad is not None]
     flat = torch.cat([g.reshape(-1) for g in grads])

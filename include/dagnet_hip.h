@@ -202,10 +202,10 @@ int dagnet_op_act_bwd(int64_t M, int32_t N, const float *dY, int64_t ldd, const 
 /* dst (+)= src for an [M,N] block (concatenations and their backward). */
 int dagnet_op_copy2d(int64_t M, int32_t N, const float *src, int64_t lds, float *dst, int64_t ldd, int32_t accumulate,
                      void *stream);
-/* Gradient of the G weight columns behind a one-hot input: dW[n][g] = sum_{m: gidx[m] = g} dP[m][n] (a weight-gradient
+/* Gradient of the G weight columns behind a one-hot input: dW[n][g] (+)= sum_{m: gidx[m] = g} dP[m][n] (a weight-gradient
  * GEMM whose second operand is generated from the indices).  workspace: dagnet_op_gemm_tn_workspace(M, N, G) floats. */
 int dagnet_op_onehot_grad(int64_t M, int32_t N, int32_t G, const float *dP, int64_t ldp, const int32_t *gidx, float *dW,
-                          int64_t ldw, float *workspace, void *stream);
+                          int64_t ldw, float *workspace, int32_t accumulate, void *stream);
 /* Replaces: nn.Softmax(dim=-1) in dec_goal / lg_goals (models/dagnet/model.py:66,100) and its backward. */
 int dagnet_op_softmax_fwd(int64_t M, int32_t N, const float *X, int64_t ldx, float *Y, int64_t ldy, void *stream);
 int dagnet_op_softmax_bwd(int64_t M, int32_t N, const float *Y, int64_t ldy, const float *dY, int64_t ldd, float *dX, int64_t ldx,

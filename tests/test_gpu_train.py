@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def hip_train_step(meta, model):
+def hip_train_step(meta, model, arena=False):
     from dagnet_amd import _ops
     from dagnet_amd.adjacency_matrix import compute_adjs, compute_adjs_distsim, compute_adjs_knnsim
     from dagnet_amd.utils import to_goals_one_hot
@@ -23,6 +23,9 @@ def hip_train_step(meta, model):
     kind = meta["kind"]
     model.train()
     opt = _ops.ClipAdam(list(model.parameters()), lr=meta["lr"], clip=meta["clip"])
+    if arena:
+        from dagnet_amd.training import attach_grad_arena
+        attach_grad_arena(model, opt)
     opt.zero_grad()
     if kind != "vrnn":
         if args.adjacency_type == 0:
@@ -59,6 +62,15 @@ def test_train_step_matches_reference(name):
     _, model, _ = cases.build_model(meta)
     model = model.to(DEV)
     out = hip_train_step(meta, model)
+    check_step(out, gold, meta["lr"], meta["clip"])
+
+
+@pytest.mark.parametrize("name", ["train_dagnet_tiny_gat", "train_dagnet_tiny_gcn", "train_vrnn_tiny"])
+def test_train_step_with_gradient_arena(name):
+    """Flat gradient buffer + in-place accumulation by the backward kernels: same step as the plain autograd path."""
+    meta, gold = cases.load_golden(name)
+    _, model, _ = cases.build_model(meta)
+    out = hip_train_step(meta, model.to(DEV), arena=True)
     check_step(out, gold, meta["lr"], meta["clip"])
 
 

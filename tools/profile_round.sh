@@ -1,12 +1,13 @@
 #!/bin/bash
 # rocprofv3 evidence for one round: kernel trace + stats, then hardware counters in separate passes
-# (never --pmc together with a trace domain).  Usage (on the GPU box, via gpurun): tools/profile_round.sh r01
+# (never --pmc together with a trace domain).  Usage (on the GPU box, via gpurun): tools/profile_round.sh r01 [workload]
 set -e
 TAG=${1:-r01}
+WORKLOAD=${2:-dagnet_bsk_4096x20}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $WORKLOAD"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ARGS > $OUT/trace.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o c -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c -- python3 $ARGS > $OUT/pmc_write.log 2>&1

@@ -59,10 +59,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
-    // column blocks vary fastest: consecutive workgroups share the A rows (L2 reuse inside an XCD round robin is
-    // irrelevant here because W is small enough to stay resident in every L2)
+    // XCD-aware tile order: workgroup w runs on XCD w % 8 (round-robin dispatch), each XCD with its own L2.  Give every
+    // XCD a contiguous range of logical tiles, column blocks fastest, so that the nbn workgroups that read the same A
+    // rows run back to back on ONE XCD (measured before: 4x the algorithmic HBM reads on the 1920 -> 960 layer, every
+    // XCD fetching every A row block).  W is small enough to stay resident in every L2.
     const int nbn = (p.N + BN - 1) / BN;
-    const int bm = blockIdx.x / nbn, bn = blockIdx.x % nbn;
+    const int64_t total = (int64_t)((p.M + BM - 1) / BM) * nbn, per_xcd = (total + 7) / 8;
+    const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tile >= total) return;
+    const int bm = (int)(tile / nbn), bn = (int)(tile % nbn);
     const int m0 = bm * BM, n0 = bn * BN;
 
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;          // this thread's (row, k) inside a 32-row slab of a chunk
@@ -277,8 +282,9 @@ template <int WM, int WN, int TM, int TN>
 static hipError_t launch_nt_cfg(const NtArgs &a, bool veca, bool vecb, bool transb, hipStream_t st) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
-    const int64_t blocks = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
-    if (blocks <= 0) return hipSuccess;
+    const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    if (tiles <= 0) return hipSuccess;
+    const int64_t blocks = (tiles + 7) / 8 * 8;          // 8 XCDs x equal ranges (the kernel drops the padding)
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 g((unsigned)blocks), t(256);
 #define DN_NT_CASE(VA, VB, TB)                                                                                        \

@@ -39,9 +39,10 @@ def pmc_traffic(workload, kernel):
             ks = json.load(open(path)).get(workload, {}).get("kernels", {})
         except (OSError, ValueError):
             continue
-        for name, v in ks.items():
-            if kernel.split(" ")[0] + "<" in name and "traffic_bytes_per_launch" in v:
-                return float(v["traffic_bytes_per_launch"])
+        hits = [float(v["traffic_bytes_per_launch"]) for name, v in ks.items()
+                if kernel.split(" ")[0] + "<" in name and "traffic_bytes_per_launch" in v]
+        if hits:
+            return max(hits)        # several instantiations of the kernel: the dominant (largest) one
     return None
 
 WORKLOADS = {

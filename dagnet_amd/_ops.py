@@ -433,10 +433,12 @@ class GatAttnFn(torch.autograd.Function):
         plan, H, F, alpha, elu = ctx.meta
         dout = _rows(dout)
         dWh = torch.empty_like(Wh)
-        da = torch.zeros_like(a)
+        da = torch.empty_like(a)
+        part = torch.empty((plan.S, H * 2 * F), dtype=torch.float32, device=Wh.device)      # per-scene contributions to da
         (w, ldw), (o, ldo), (g, ldg), (dw, ldd) = _m(Wh), _m(out), _m(dout), _m(dWh)
-        _check(_lib().dagnet_op_gat_attn_bwd(plan._h, _p(adj), _adj_ld(adj), w, ldw, _p(a), H, F, alpha, int(elu), o, ldo, g, ldg, dw, ldd, _p(da),
-                                             _stream(Wh.device)))
+        _check(_lib().dagnet_op_gat_attn_bwd(plan._h, _p(adj), _adj_ld(adj), w, ldw, _p(a), H, F, alpha, int(elu), o, ldo, g, ldg, dw, ldd,
+                                             _p(part), _stream(Wh.device)))
+        colsum(part, da)
         return dWh, da, None, None, None, None, None, None
 
 

@@ -1433,15 +1433,15 @@ extern "C" int dagnet_op_gat_attn_fwd(const dagnet_plan *p, const float *adj, in
 }
 extern "C" int dagnet_op_gat_attn_bwd(const dagnet_plan *p, const float *adj, int64_t adj_ld, const float *Wh, int64_t ldw, const float *a, int32_t H,
                                       int32_t F, float alpha, int32_t elu, const float *Out, int64_t ldo, const float *dOut, int64_t ldd,
-                                      float *dWh, int64_t ldg, float *da, void *stream) {
+                                      float *dWh, int64_t ldg, float *da_part, void *stream) {
     if (int rc = op_plan(p)) return rc;
-    OP_NEED(adj && Wh && a && dOut && dWh && da && (!elu || Out) && H >= 1 && F >= 1, "bad argument");
+    OP_NEED(adj && Wh && a && dOut && dWh && da_part && (!elu || Out) && H >= 1 && F >= 1, "bad argument");
     if (dn_t_gat_lds_bytes(p->AS, F, 1) > 64 * 1024)
         return fail(DAGNET_ERR_CAPACITY, "graph attention backward with %d agents x %d features does not fit the LDS tile of the training kernels", p->AS, F);
     const int64_t *off;
     if (int rc = op_adj(p, adj_ld, &off)) return rc;
     HIP_TRY(dn_t_gat_attn_bwd(p->d_scene_ptr, off, p->S, p->AS, adj_ld, adj, Wh, ldw, a, H, F, alpha, elu, Out, ldo, dOut, ldd, dWh,
-                              ldg, da, OP_ST));
+                              ldg, da_part, OP_ST));
     return DAGNET_OK;
 }
 extern "C" int dagnet_op_adj_matmul(const dagnet_plan *p, int32_t F, const float *adj, int64_t adj_ld, const float *X, int64_t ldx, const float *bias,

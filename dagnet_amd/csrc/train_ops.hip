@@ -332,26 +332,27 @@ struct Scenes {
     int64_t ld;                // 0: compact blocks (row stride = the scene's agent count); else the dense row stride N
 };
 
+#define GAT_T 64
 // GAT attention of one layer (gat_layers.py:25-40) for H heads of width F stacked along the columns of Wh:
 //   s1_i = Wh_i . a[:F], s2_j = Wh_j . a[F:], e_ij = leakyrelu(s1_i + s2_j) where adj_ij > 0, att = softmax_j, out = att Wh (elu)
 // grid (S, H); dynamic LDS: Wh [n][F] | s1 [n] | s2 [n] | att [n][n].  Pair (i,j) and (row, feature) loops are spread over
-// the 128 threads; only the O(n) row normalisations run on n threads.
+// the 64 threads of ONE wave per (scene, head) (single-wave workgroups: barriers cost nothing, many scenes per CU); only the O(n) row normalisations run on n threads.
 __device__ __forceinline__ void gat_logits(int n, int F, int64_t rld, const float *wh, const float *ah, const float *ablk, float alpha,
                                            float *s1, float *s2, float *att, int tid) {
-    for (int e = tid; e < 2 * n; e += 128) {
+    for (int e = tid; e < 2 * n; e += GAT_T) {
         const int i = e >> 1, w = e & 1;
         float u = 0.f;
         for (int f = 0; f < F; ++f) u += wh[i * F + f] * ah[w * F + f];
         (w ? s2 : s1)[i] = u;
     }
     __syncthreads();
-    for (int e = tid; e < n * n; e += 128) {
+    for (int e = tid; e < n * n; e += GAT_T) {
         const int i = e / n, j = e - i * n;
         const float v = s1[i] + s2[j];
         att[e] = ablk[i * rld + j] > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 128) {
+    for (int i = tid; i < n; i += GAT_T) {
         float mx = -INFINITY;
         for (int j = 0; j < n; ++j) mx = fmaxf(mx, att[i * n + j]);
         float sum = 0.f;
@@ -366,7 +367,7 @@ __device__ __forceinline__ void gat_logits(int n, int F, int64_t rld, const floa
     __syncthreads();
 }
 
-__global__ __launch_bounds__(128) void gat_attn_fwd_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
+__global__ __launch_bounds__(GAT_T) void gat_attn_fwd_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
                                                           int64_t ldw, const float *__restrict__ a, int F, float alpha, int elu,
                                                           float *__restrict__ Out, int64_t ldo) {
     extern __shared__ float sm[];
@@ -377,10 +378,10 @@ __global__ __launch_bounds__(128) void gat_attn_fwd_kernel(Scenes sc, const floa
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
-    for (int e = tid; e < n * F; e += 128) wh[e] = Wh[(int64_t)(b + e / F) * ldw + hd * F + e % F];
+    for (int e = tid; e < n * F; e += GAT_T) wh[e] = Wh[(int64_t)(b + e / F) * ldw + hd * F + e % F];
     __syncthreads();
     gat_logits(n, F, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
-    for (int e = tid; e < n * F; e += 128) {
+    for (int e = tid; e < n * F; e += GAT_T) {
         const int i = e / F, f = e % F;
         float acc = 0.f;
         for (int j = 0; j < n; ++j) acc += att[i * n + j] * wh[j * F + f];
@@ -390,11 +391,12 @@ __global__ __launch_bounds__(128) void gat_attn_fwd_kernel(Scenes sc, const floa
 }
 
 // backward of the above.  dynamic LDS: Wh [n][F] | dO [n][F] | s1 | s2 | ds1 | ds2 | dot [n] each | att [n][n] | dpre [n][n]
-// da (H x 2F) is accumulated with atomics over the scenes.
-__global__ __launch_bounds__(128) void gat_attn_bwd_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
+// da_part [S][H x 2F]: this scene's contribution to the gradient of a; the caller sums the column (same-address atomics
+// over thousands of scenes serialise in the L2: 260 us per call before, and the sum order was not fixed).
+__global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
                                                           int64_t ldw, const float *__restrict__ a, int F, float alpha, int elu,
                                                           const float *__restrict__ Out, int64_t ldo, const float *__restrict__ dOut,
-                                                          int64_t ldd, float *__restrict__ dWh, int64_t ldg, float *__restrict__ da) {
+                                                          int64_t ldd, float *__restrict__ dWh, int64_t ldg, float *__restrict__ da_part) {
     extern __shared__ float sm[];
     const int s = blockIdx.x, hd = blockIdx.y;
     const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b;
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(128) void gat_attn_bwd_kernel(Scenes sc, const floa
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
-    for (int e = tid; e < n * F; e += 128) {
+    for (int e = tid; e < n * F; e += GAT_T) {
         const int64_t row = b + e / F;
         const int col = hd * F + e % F;
         wh[e] = Wh[row * ldw + col];
@@ -415,45 +417,45 @@ __global__ __launch_bounds__(128) void gat_attn_bwd_kernel(Scenes sc, const floa
     __syncthreads();
     gat_logits(n, F, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
     // d att_ij = dO_i . Wh_j
-    for (int e = tid; e < n * n; e += 128) {
+    for (int e = tid; e < n * n; e += GAT_T) {
         const int i = e / n, j = e - i * n;
         float d = 0.f;
         for (int f = 0; f < F; ++f) d += dO[i * F + f] * wh[j * F + f];
         dpre[e] = d;
     }
     __syncthreads();
-    for (int i = tid; i < n; i += 128) {
+    for (int i = tid; i < n; i += GAT_T) {
         float acc = 0.f;
         for (int j = 0; j < n; ++j) acc += att[i * n + j] * dpre[i * n + j];
         dot[i] = acc;
     }
     __syncthreads();
     // d e_ij = att_ij (d att_ij - sum_k att_ik d att_ik), through the leaky relu
-    for (int e = tid; e < n * n; e += 128) {
+    for (int e = tid; e < n * n; e += GAT_T) {
         const int i = e / n, j = e - i * n;
         const float v = s1[i] + s2[j];
         dpre[e] = att[e] * (dpre[e] - dot[i]) * (v > 0.f ? 1.f : alpha);
     }
     __syncthreads();
-    for (int e = tid; e < 2 * n; e += 128) {
+    for (int e = tid; e < 2 * n; e += GAT_T) {
         const int i = e >> 1;
         float acc = 0.f;
         if (e & 1) { for (int k = 0; k < n; ++k) acc += dpre[k * n + i]; ds2[i] = acc; }
         else       { for (int k = 0; k < n; ++k) acc += dpre[i * n + k]; ds1[i] = acc; }
     }
     __syncthreads();
-    for (int e = tid; e < n * F; e += 128) {
+    for (int e = tid; e < n * F; e += GAT_T) {
         const int j = e / F, f = e % F;
         float acc = ds1[j] * ah[f] + ds2[j] * ah[F + f];
         for (int i = 0; i < n; ++i) acc += att[i * n + j] * dO[i * F + f];
         dWh[(int64_t)(b + j) * ldg + hd * F + f] = acc;
     }
-    for (int f = tid; f < 2 * F; f += 128) {
+    for (int f = tid; f < 2 * F; f += GAT_T) {
         const float *ds = f < F ? ds1 : ds2;
         const int ff = f < F ? f : f - F;
         float acc = 0.f;
         for (int i = 0; i < n; ++i) acc += ds[i] * wh[i * F + ff];
-        atomicAdd(da + (int64_t)hd * 2 * F + f, acc);
+        da_part[((int64_t)s * gridDim.y + hd) * 2 * F + f] = acc;
     }
 }
 
@@ -670,18 +672,18 @@ extern "C" hipError_t dn_t_gat_attn_fwd(const int32_t *scene_ptr, const int64_t 
     const int64_t lds = dn_t_gat_lds_bytes(n_max, F, 0);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     tops::Scenes sc{scene_ptr, off_compact, S, adj_ld};
-    hipLaunchKernelGGL(tops::gat_attn_fwd_kernel, dim3(S, H), dim3(128), (size_t)lds, st, sc, adj, Wh, ldw, a, F, alpha, elu, Out, ldo);
+    hipLaunchKernelGGL(tops::gat_attn_fwd_kernel, dim3(S, H), dim3(GAT_T), (size_t)lds, st, sc, adj, Wh, ldw, a, F, alpha, elu, Out, ldo);
     return hipGetLastError();
 }
 extern "C" hipError_t dn_t_gat_attn_bwd(const int32_t *scene_ptr, const int64_t *off_compact, int S, int n_max, int64_t adj_ld, const float *adj,
                                         const float *Wh, int64_t ldw, const float *a, int H, int F, float alpha, int elu, const float *Out,
-                                        int64_t ldo, const float *dOut, int64_t ldd, float *dWh, int64_t ldg, float *da, hipStream_t st) {
+                                        int64_t ldo, const float *dOut, int64_t ldd, float *dWh, int64_t ldg, float *da_part, hipStream_t st) {
     if (S == 0) return hipSuccess;
     const int64_t lds = dn_t_gat_lds_bytes(n_max, F, 1);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     tops::Scenes sc{scene_ptr, off_compact, S, adj_ld};
-    hipLaunchKernelGGL(tops::gat_attn_bwd_kernel, dim3(S, H), dim3(128), (size_t)lds, st, sc, adj, Wh, ldw, a, F, alpha, elu, Out, ldo, dOut,
-                       ldd, dWh, ldg, da);
+    hipLaunchKernelGGL(tops::gat_attn_bwd_kernel, dim3(S, H), dim3(GAT_T), (size_t)lds, st, sc, adj, Wh, ldw, a, F, alpha, elu, Out, ldo, dOut,
+                       ldd, dWh, ldg, da_part);
     return hipGetLastError();
 }
 extern "C" hipError_t dn_t_adj_matmul(const int32_t *scene_ptr, const int64_t *off_compact, const int32_t *row_scene, int S, int64_t Nrows,

@@ -246,12 +246,13 @@ int dagnet_op_bn_bwd(int64_t M, int32_t N, const float *X, int64_t ldx, const fl
                      float *dbeta, int32_t accumulate, float *sums, float *workspace, void *stream);
 /* Replaces: GraphAttentionLayer.forward (gat_layers.py:25-40) after Wh = x W, per scene of the plan, for H heads of width F
  * stacked along the columns of Wh; a [H][2F].  adj: compact block-diagonal (adj_ld 0) or dense [N,N] (adj_ld N).
- * Backward: dWh and da (accumulated over the scenes with atomics; da must be zeroed by the caller). */
+ * Backward: dWh and da_part [S][H*2F], every scene's contribution to the gradient of a (sum its columns with
+ * dagnet_op_colsum). */
 int dagnet_op_gat_attn_fwd(const dagnet_plan *p, const float *adj, int64_t adj_ld, const float *Wh, int64_t ldw, const float *a,
                            int32_t H, int32_t F, float alpha, int32_t elu, float *Out, int64_t ldo, void *stream);
 int dagnet_op_gat_attn_bwd(const dagnet_plan *p, const float *adj, int64_t adj_ld, const float *Wh, int64_t ldw, const float *a,
                            int32_t H, int32_t F, float alpha, int32_t elu, const float *Out, int64_t ldo, const float *dOut,
-                           int64_t ldd, float *dWh, int64_t ldg, float *da, void *stream);
+                           int64_t ldd, float *dWh, int64_t ldg, float *da_part, void *stream);
 /* Replaces: torch.spmm(adj, support) + bias of GraphConvolution.forward (gcn_layers.py:20-26) per scene; transpose = 1
  * multiplies by adj^T (the backward). */
 int dagnet_op_adj_matmul(const dagnet_plan *p, int32_t F, const float *adj, int64_t adj_ld, const float *X, int64_t ldx,

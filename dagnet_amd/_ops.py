@@ -38,7 +38,7 @@ def _lib():
         lib.dagnet_op_gemm.argtypes = [vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, f32, i32, vp, vp, i64, i64, vp]
         lib.dagnet_op_gemm_tn_workspace.argtypes = [i32, i32, i32]
         lib.dagnet_op_gemm_tn_workspace.restype = i64
-        lib.dagnet_op_gemm_tn.argtypes = [vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i32, vp]
+        lib.dagnet_op_gemm_tn.argtypes = [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp, i32, vp]
         lib.dagnet_op_act_bwd.argtypes = [i64, i32, vp, i64, vp, i64, vp, i64, i32, f32, vp]
         lib.dagnet_op_copy2d.argtypes = [i64, i32, vp, i64, vp, i64, i32, vp]
         lib.dagnet_op_onehot_grad.argtypes = [i64, i32, i32, vp, i64, vp, vp, i64, vp, i32, vp]
@@ -123,12 +123,12 @@ def gemm(A, B, C_out, *, transb=False, bias=None, act=ACT_NONE, slope=0.01, accu
                                  gather, _p(gidx), gs_g, gs_n, _stream(A.device)))
 
 
-def gemm_tn(A, B, C_out, accumulate=False):
-    """C[N,K] (+)= A[M,N]^T B[M,K]"""
+def gemm_tn(A, B, C_out, accumulate=False, dbias=None):
+    """C[N,K] (+)= A[M,N]^T B[M,K];  dbias [N] (+)= column sums of A (same pass)."""
     (a, lda), (b, ldb), (c, ldc) = _m(A, "A"), _m(B, "B"), _m(C_out, "C")
     M, N, K = A.shape[0], A.shape[1], B.shape[1]
     ws = _ws(A.device, _lib().dagnet_op_gemm_tn_workspace(M, N, K))
-    _check(_lib().dagnet_op_gemm_tn(a, lda, b, ldb, c, ldc, M, N, K, _p(ws), int(accumulate), _stream(A.device)))
+    _check(_lib().dagnet_op_gemm_tn(a, lda, b, ldb, c, ldc, _p(dbias), M, N, K, _p(ws), int(accumulate), _stream(A.device)))
 
 
 def colsum(X, out, accumulate=False):
@@ -203,8 +203,13 @@ class LinearFn(torch.autograd.Function):
             sink = _sink(ctx.W_param)
             dW = sink if sink is not None else torch.zeros_like(W)
             acc = sink is not None
-            for x, c0 in zip(xs, cols):
-                gemm_tn(dpre, x, dW[:, c0:c0 + x.shape[1]], accumulate=acc)
+            # the bias gradient rides on the first weight-gradient GEMM (same pass over dpre) when both accumulate alike
+            bsink = _sink(ctx.b_param) if has_b and ctx.needs_input_grad[1] else None
+            fused_b = None
+            if has_b and ctx.needs_input_grad[1] and (bsink is not None) == acc:
+                fused_b = bsink if acc else torch.empty(N, dtype=torch.float32, device=y.device)
+            for s_, (x, c0) in enumerate(zip(xs, cols)):
+                gemm_tn(dpre, x, dW[:, c0:c0 + x.shape[1]], accumulate=acc, dbias=fused_b if s_ == 0 else None)
             if gidx is not None:
                 (dp, ldp) = _m(dpre)
                 ws = _ws(y.device, _lib().dagnet_op_gemm_tn_workspace(M, N, gdim))
@@ -212,7 +217,9 @@ class LinearFn(torch.autograd.Function):
                                                     int(acc), _stream(y.device)))
             if acc:
                 dW = None
-        if has_b and ctx.needs_input_grad[1]:
+        if has_b and ctx.needs_input_grad[1] and ctx.needs_input_grad[0] and fused_b is not None:
+            db = None if acc else fused_b
+        elif has_b and ctx.needs_input_grad[1]:
             sink = _sink(ctx.b_param)
             if sink is not None:
                 colsum(dpre, sink, accumulate=True)

@@ -1238,7 +1238,7 @@ extern "C" int64_t dn_gemm_tn_workspace(int M, int N, int K);
 extern "C" hipError_t dn_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int M, int N, int K,
                                  float *part, int accumulate, hipStream_t st);
 extern "C" hipError_t dn_gemm_tn_idx(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, float *C, int64_t ldc,
-                                     int M, int N, int K, float *part, int accumulate, hipStream_t st);
+                                     float *dbias, int M, int N, int K, float *part, int accumulate, hipStream_t st);
 extern "C" hipError_t dn_t_act_bwd(int64_t, int, const float *, int64_t, const float *, int64_t, float *, int64_t, int, float, hipStream_t);
 extern "C" hipError_t dn_t_copy2d(int64_t, int, const float *, int64_t, float *, int64_t, int, hipStream_t);
 extern "C" hipError_t dn_t_softmax_fwd(int64_t, int, const float *, int64_t, float *, int64_t, hipStream_t);
@@ -1293,13 +1293,13 @@ extern "C" int dagnet_op_gemm(const float *A, int64_t lda, const float *B, int64
     return DAGNET_OK;
 }
 extern "C" int64_t dagnet_op_gemm_tn_workspace(int32_t M, int32_t N, int32_t K) { return dn_gemm_tn_workspace(M, N, K); }
-extern "C" int dagnet_op_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int32_t M, int32_t N,
-                                 int32_t K, float *workspace, int32_t accumulate, void *stream) {
+extern "C" int dagnet_op_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float *dbias, int32_t M,
+                                 int32_t N, int32_t K, float *workspace, int32_t accumulate, void *stream) {
     OP_NEED(M >= 0 && N >= 0 && K >= 0, "negative dimension");
     if (N == 0 || K == 0) return DAGNET_OK;
     OP_NEED(A && B && C && workspace, "null operand");
     OP_NEED(lda >= N && ldb >= K && ldc >= K, "row stride smaller than the row");
-    HIP_TRY(dn_gemm_tn(A, lda, B, ldb, C, ldc, M, N, K, workspace, accumulate, OP_ST));
+    HIP_TRY(dn_gemm_tn_idx(A, lda, B, ldb, nullptr, C, ldc, dbias, M, N, K, workspace, accumulate, OP_ST));
     return DAGNET_OK;
 }
 extern "C" int dagnet_op_act_bwd(int64_t M, int32_t N, const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp,
@@ -1319,7 +1319,7 @@ extern "C" int dagnet_op_onehot_grad(int64_t M, int32_t N, int32_t G, const floa
     OP_NEED(M >= 0 && N >= 0 && G >= 0 && M <= 0x7fffffffLL && (M * N == 0 || (dP && gidx && dW && workspace)), "bad argument");
     if (M * N == 0 || G == 0) return DAGNET_OK;
     // dW[n][g] = sum_m dP[m][n] * onehot(gidx[m])[g]: the weight-gradient GEMM with a generated one-hot operand
-    HIP_TRY(dn_gemm_tn_idx(dP, ldp, nullptr, 0, gidx, dW, ldw, (int)M, N, G, workspace, accumulate, OP_ST));
+    HIP_TRY(dn_gemm_tn_idx(dP, ldp, nullptr, 0, gidx, dW, ldw, nullptr, (int)M, N, G, workspace, accumulate, OP_ST));
     return DAGNET_OK;
 }
 extern "C" int dagnet_op_softmax_fwd(int64_t M, int32_t N, const float *X, int64_t ldx, float *Y, int64_t ldy, void *stream) {

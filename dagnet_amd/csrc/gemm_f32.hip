@@ -182,6 +182,7 @@ struct TnArgs {
     int M, N, K;
     int rows_per_split;               // multiple of 32
     const int32_t *bidx;              // not null: B is one-hot, B[m][k] = (bidx[m] == k)   (gradients of one-hot inputs)
+    float *bias_part;                 // not null: [splits][N] column sums of A over this split's rows (bias gradient)
 };
 
 // C_split[n][k] = sum over this split's rows m of A[m][n] * B[m][k].  Workgroup tile 64 x 64 (2x2 waves, 1 tile each),
@@ -196,6 +197,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
     const int lrow = tid >> 4, lc4 = (tid & 15) * 4;          // 16 rows x 16 float4 per pass, 2 passes per 32-row chunk
     const bool vecA = (p.lda & 3) == 0, vecB = (p.ldb & 3) == 0;
     f32x4 ga[2], gb[2];
+    f32x4 bsum = {0, 0, 0, 0};                               // this thread's share of the column sums of A
+    const bool want_bias = p.bias_part != nullptr && k0 == 0;
     auto ld4 = [&](const float *base, int64_t ld, int row, int col, int ncol, bool vec) {
         f32x4 v = {0, 0, 0, 0};
         if (row < mend) {
@@ -213,6 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             ga[i] = ld4(p.A, p.lda, m + lrow + 16 * i, n0 + lc4, p.N, vecA);
+            if (want_bias) bsum += ga[i];
             if (p.bidx) {
                 const int row = m + lrow + 16 * i;
                 const int hot = row < mend ? p.bidx[row] - (k0 + lc4) : -1;
@@ -248,6 +252,17 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(sA[buf][2 * kk + lh][wm * 32 + lr], sB[buf][2 * kk + lh][wn * 32 + lr], acc, 0, 0, 0);
         if (c + 1 < nchunk) sstore(buf ^ 1);
         __syncthreads();
+    }
+    if (want_bias) {       // 16 row lanes x 64 columns -> column sums (the loop above ended with a barrier: sA is free)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) sA[0][lrow][lc4 + c] = bsum[c];
+        __syncthreads();
+        if (tid < 64 && n0 + tid < p.N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += sA[0][r][tid];
+            p.bias_part[(int64_t)blockIdx.y * p.N + n0 + tid] = t;
+        }
     }
     float *C = p.C + (int64_t)blockIdx.y * p.N * p.ldc;
     const int col = k0 + wn * 32 + lr;
@@ -338,25 +353,30 @@ extern "C" int64_t dn_gemm_tn_splits(int M, int N, int K) {
     if (s > cap) s = cap;
     return s < 1 ? 1 : (s > 512 ? 512 : s);
 }
-extern "C" int64_t dn_gemm_tn_workspace(int M, int N, int K) { return dn_gemm_tn_splits(M, N, K) * (int64_t)N * K; }
+extern "C" int64_t dn_gemm_tn_workspace(int M, int N, int K) { return dn_gemm_tn_splits(M, N, K) * ((int64_t)N * K + N); }
+// dbias (nullable): [N] (+)= column sums of A, computed by the same pass over A (the bias gradient of the layer)
 extern "C" hipError_t dn_gemm_tn_idx(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, float *C, int64_t ldc,
-                                     int M, int N, int K, float *part, int accumulate, hipStream_t st) {
+                                     float *dbias, int M, int N, int K, float *part, int accumulate, hipStream_t st) {
     if (N <= 0 || K <= 0) return hipSuccess;
     const int splits = (int)dn_gemm_tn_splits(M, N, K);
     int rows = (M + splits - 1) / splits;
     rows = (rows + 31) & ~31;
     if (rows < 32) rows = 32;
-    gemm::TnArgs a{A, lda, B, ldb, part, K, M, N, K, rows, bidx};
+    float *bias_part = dbias ? part + (int64_t)splits * N * K : nullptr;
+    gemm::TnArgs a{A, lda, B, ldb, part, K, M, N, K, rows, bidx, bias_part};
     const int blocks = ((N + 63) / 64) * ((K + 63) / 64);
     hipLaunchKernelGGL(gemm::gemm_tn_kernel, dim3(blocks, splits), dim3(256), 0, st, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int64_t n = (int64_t)N * K;
     hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, splits, N, K, C, ldc, accumulate);
+    if (dbias)
+        hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, bias_part, splits, 1, N, dbias,
+                           (int64_t)N, accumulate);
     return hipGetLastError();
 }
 
 extern "C" hipError_t dn_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int M, int N, int K,
                                  float *part, int accumulate, hipStream_t st) {
-    return dn_gemm_tn_idx(A, lda, B, ldb, nullptr, C, ldc, M, N, K, part, accumulate, st);
+    return dn_gemm_tn_idx(A, lda, B, ldb, nullptr, C, ldc, nullptr, M, N, K, part, accumulate, st);
 }

@@ -191,11 +191,11 @@ int dagnet_categorical(int32_t N, int32_t G, const float *d_weights, const float
 int dagnet_op_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int32_t transb, const float *bias, float *C,
                    int64_t ldc, int32_t M, int32_t N, int32_t K, int32_t act, float slope, int32_t accumulate,
                    const float *gather, const int32_t *gidx, int64_t gs_g, int64_t gs_n, void *stream);
-/* Weight gradients: C[N,K] (+)= A[M,N]^T B[M,K], deterministic two-pass reduction over the rows.
- * workspace: dagnet_op_gemm_tn_workspace(M, N, K) floats. */
+/* Weight gradients: C[N,K] (+)= A[M,N]^T B[M,K], deterministic two-pass reduction over the rows; dbias (nullable):
+ * [N] (+)= column sums of A from the same pass (the bias gradient).  workspace: dagnet_op_gemm_tn_workspace(M, N, K) floats. */
 int64_t dagnet_op_gemm_tn_workspace(int32_t M, int32_t N, int32_t K);
-int dagnet_op_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int32_t M, int32_t N,
-                      int32_t K, float *workspace, int32_t accumulate, void *stream);
+int dagnet_op_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float *dbias, int32_t M,
+                      int32_t N, int32_t K, float *workspace, int32_t accumulate, void *stream);
 /* dP = dY * act'(.) through the saved layer output Y (backward of LeakyReLU / ReLU / tanh). */
 int dagnet_op_act_bwd(int64_t M, int32_t N, const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp,
                       int32_t act, float slope, void *stream);

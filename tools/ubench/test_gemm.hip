@@ -39,10 +39,13 @@ static int check_tn(int M, int N, int K) {
   CHECK(hipMalloc(&dA, A.size() * 4)); CHECK(hipMalloc(&dB, B.size() * 4)); CHECK(hipMalloc(&dC, C.size() * 4));
   CHECK(hipMalloc(&dP, dn_gemm_tn_workspace(M, N, K) * 4));
   CHECK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice)); CHECK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
-  CHECK(dn_gemm_tn(dA, lda, dB, ldb, dC, K, M, N, K, dP, 0, 0));
+  float *dBias; CHECK(hipMalloc(&dBias, N * 4));
+  CHECK(dn_gemm_tn_idx(dA, lda, dB, ldb, nullptr, dC, K, dBias, M, N, K, dP, 0, 0));
   CHECK(hipDeviceSynchronize());
   CHECK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<float> bias(N); CHECK(hipMemcpy(bias.data(), dBias, N * 4, hipMemcpyDeviceToHost));
   int bad = 0;
+  for (int n = 0; n < N; ++n) { double r = 0; for (int m = 0; m < M; ++m) r += A[(size_t)m * lda + n]; if ((float)r != bias[n]) ++bad; }
   for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) {
     double r = 0;
     for (int m = 0; m < M; ++m) r += (double)A[(size_t)m * lda + n] * B[(size_t)m * ldb + k];

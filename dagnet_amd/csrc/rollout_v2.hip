@@ -526,19 +526,21 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.prior0.w[0]);
             finish<0, GT>(gc, wp, W.lg_goals, 0, lh);
             softmax_feat<GT>(gc, R.G, lh);
-            // categorical draw: argmax_g exp(p_g) / q_g, q ~ Exp(1)
+            // categorical draw: argmax_g exp(p_g) / q_g, q ~ Exp(1).  Branch-free (selects only): features are visited in
+            // increasing order within a lane, so a strict '>' keeps the first maximum; out-of-range features score -1.
             float best = -1.f;
             int bi = 0x7fffffff;
+            const int Gm1 = R.G - 1;
+            const int64_t qrow = ((((int64_t)krow * R.T + t) * NK + (live ? grow : 0)) * R.G);
 #pragma unroll
             for (int nt = 0; nt < GT; ++nt)
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const int f0 = nt * 32 + 8 * a + 4 * lh;
                     float q4[4];
-                    if (R.q) {
+                    if (R.q) {      // uniform branch; loads are clamped into the row instead of predicated
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            q4[i] = (live && f0 + i < R.G) ? R.q[(((int64_t)krow * R.T + t) * NK + grow) * R.G + f0 + i] : 1.f;
+                        for (int i = 0; i < 4; ++i) q4[i] = R.q[qrow + min(f0 + i, Gm1)];
                     } else {
                         const uint4 u = philox4x32(make_uint4(rngrow, (uint32_t)t, (uint32_t)(f0 >> 2), 1u),
                                                       make_uint2((uint32_t)R.seed, (uint32_t)(R.seed >> 32)));
@@ -549,10 +551,11 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int f = f0 + i;
-                        if (f < R.G) {
-                            const float v = fexp(gc[nt][4 * a + i]) * frcp(q4[i]);
-                            if (v > best || (v == best && f < bi)) { best = v; bi = f; }
-                        }
+                        float v = fexp(gc[nt][4 * a + i]) * frcp(q4[i]);
+                        v = f <= Gm1 ? v : -1.f;
+                        const bool take = v > best;
+                        best = take ? v : best;
+                        bi = take ? f : bi;
                     }
                 }
             {

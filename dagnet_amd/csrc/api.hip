@@ -27,6 +27,7 @@ extern "C" hipError_t dn_launch_best_of_k(const int32_t *scene_ptr, int S, int N
                                           double *sums, hipStream_t st);
 extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, const V2Weights *w, const V2Run *r, hipStream_t st);
 extern "C" int dn_v2_has(int model, int n_layers, int z_dim);
+extern "C" hipError_t dn_launch_forward_v2(int model, int n_layers, int z_dim, const V2Weights *w, const V2Run *r, hipStream_t st);
 extern "C" hipError_t dn_launch_loss_finalize(int n_tiles, int N, const double *part, double *losses, hipStream_t st);
 extern "C" hipError_t dn_launch_abs_errors(int T, int N, const float *pred, const float *gt, float *ade, float *fde, hipStream_t st);
 extern "C" hipError_t dn_launch_scene_min_sum(const int32_t *scene_ptr, int S, int N, int K, const float *ade, const float *fde,
@@ -618,6 +619,14 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
     }
     W.prior2 = v2_linear(pk, "prior.2", H, H, {{0, H}});
     W.prior_ml = v2_pair(pk, "prior_mean", "prior_logvar", Z, H);
+    if (!ext) {     // teacher-forced pass (forward_v2.hip)
+        if (dag) W.enc0 = v2_linear(pk, "enc.0", H, H + G + R, {{0, H}, {H + G, R}}, H, G);
+        else W.enc0 = v2_linear(pk, "enc.0", H, H + R, {{0, H}, {H, R}});
+        W.enc2 = v2_linear(pk, "enc.2", H, H, {{0, H}});
+        W.enc_ml = v2_pair(pk, "enc_mean", "enc_logvar", Z, H);
+        DnRaw dl = pack_raw_linear(pk, "dec_logvar", 2, H);
+        W.dec_logvar_w = dl.w; W.dec_logvar_b = dl.b;
+    }
     W.dec2 = v2_linear(pk, "dec.2", H, H, {{0, H}});
     for (int l = 0; l < c.n_layers; ++l) W.gru[l] = v2_gru(pk, l, R, H);
     if (graph) {
@@ -930,7 +939,7 @@ extern "C" int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_
     up(reinterpret_cast<void **>(&p->d_row_scene), row_scene.data(), sizeof(int32_t) * N);
     up(reinterpret_cast<void **>(&p->d_off_dense), offd.data(), sizeof(int64_t) * S);
     up(reinterpret_cast<void **>(&p->d_off_compact), offc.data(), sizeof(int64_t) * S);
-    if (m && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_loss_part), sizeof(double) * 3 * p->n_tiles);
+    if (m && e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&p->d_loss_part), sizeof(double) * 3 * std::max(p->n_tiles, p->n_tiles2));
     if (big && e == hipSuccess) {
         p->gslab = (int64_t)3 * pad32(m->dims.G) * M;
         p->gblocks = std::min(p->n_tiles, 1024);
@@ -1125,11 +1134,28 @@ extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32
     const bool dag = m->dims.model == DAGNET_MODEL_DAGNET;
     if (dag && (!d_traj || !d_goals)) return fail(DAGNET_ERR_INVALID, "traj and goals are required for DAG-Net");
     if (int rc = check_plan(m, p)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
     DnParams P;
     fill_common(P, m, p);
     if (m->dims.model != DAGNET_MODEL_VRNN) {
         const int rc = set_adj(P, p, d_adj, adj_dense_ld);
         if (rc) return rc;
+    }
+    if (m->v2 && p->n_tiles2 > 0 && !getenv("DAGNET_FORCE_GENERIC")) {
+        // register-resident teacher-forced pass (forward_v2.hip); GAT consumes only the adjacency's support
+        V2Run r;
+        memset(&r, 0, sizeof(r));
+        r.wp = m->d_wp;
+        r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
+        r.S = p->S; r.N = p->N; r.K = 1; r.T = T; r.n_tiles = p->n_tiles2;
+        r.G = m->dims.G; r.D = m->dims.D; r.adj_type = m->dims.adj_type; r.alpha = m->dims.alpha; r.sigma = m->dims.sigma;
+        r.eps = d_eps; r.seed = seed; r.h_out = d_h_out;
+        r.traj = d_traj; r.traj_rel = d_traj_rel; r.goals = d_goals;
+        r.adj = P.r.adj; r.adj_ld = P.r.adj_ld; r.adj_tstride = P.r.adj_tstride; r.adj_off = P.r.adj_off;
+        r.loss_part = p->d_loss_part;
+        HIP_TRY(dn_launch_forward_v2(m->dims.model, m->dims.L, m->dims.Z, m->d_w2, &r, st));
+        HIP_TRY(dn_launch_loss_finalize(p->n_tiles2, p->N, p->d_loss_part, d_losses, st));
+        return DAGNET_OK;
     }
     P.r.T = T;
     P.r.traj = d_traj; P.r.traj_rel = d_traj_rel; P.r.goals = d_goals;
@@ -1137,7 +1163,6 @@ extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32
     P.r.seed = seed;
     P.r.loss_part = p->d_loss_part;
     P.r.h_out = d_h_out;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     HIP_TRY(dn_launch_rollout(1, p->d_static, &P.r, (size_t)p->lds.total * 4, st));
     HIP_TRY(dn_launch_loss_finalize(p->n_tiles, p->N, p->d_loss_part, d_losses, st));
     return DAGNET_OK;

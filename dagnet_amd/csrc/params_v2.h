@@ -40,6 +40,9 @@ struct V2Weights {
     V2Lin dec_goal0, dec_goal2;
     V2Gat g_goal;
     V2Lin lg_goals;
+    // teacher-forced pass only (forward_v2.hip)
+    V2Lin enc0, enc2, enc_ml;
+    int32_t dec_logvar_w, dec_logvar_b;   // raw [2][H], [2]
 };
 
 struct V2Run {
@@ -59,6 +62,14 @@ struct V2Run {
     // model 3 (goal head outside the kernel): steps [t_begin, t_end) of T, state per (sample, row), written back
     int32_t t_begin, t_end;
     float *h_out, *x_out;
+    // teacher-forced pass (forward_v2.hip): inputs [T,N,.], adjacency per step (dense ld = N or compact ld = 0), per-tile
+    // loss partials [n_tiles][3] (KLD, NLL, CE row sums)
+    const float *traj, *traj_rel;
+    const int32_t *goals;
+    const float *adj;
+    int64_t adj_ld, adj_tstride;
+    const int64_t *adj_off;
+    double *loss_part;
     long long *prof;                 // DN_PROFILE builds: per-phase cycle counters of tile 0
     float *dbg;                      // debug builds: tile dumps of the first step of tile 0 (else NULL)
 };

@@ -19,345 +19,9 @@
 // Reference behaviour: models/dagnet/model.py:196-270, models/avrnn/model.py:163-215,
 // models/baseline/model.py:135-170, models/dagnet/gat/gat_layers.py:25-40, gat_model.py:18-22,
 // models/utils/adjacency_matrix.py:21-28,49-58, models/utils/utils.py:200-207.
-#include <hip/hip_runtime.h>
-#include <math.h>
-#include "params_v2.h"
-#include "rng.h"
-
-typedef float T16 __attribute__((ext_vector_type(16)));
-
-#define FR(r) (((r) & 3) + 8 * ((r) >> 2))
-#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-// raw buffer loads declared straight on the LLVM intrinsics: clang 22's
-// __builtin_amdgcn_raw_buffer_load_b128 collapses to a single dword here (all four lanes of the
-// result alias element 0), these forms select buffer_load_dwordx4 / _dword as expected.
-__device__ f32x4 dn_buffer_load_f32x4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
-__device__ float dn_buffer_load_f32(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
-
-#ifndef DN_V2_DEPTH
-#define DN_V2_DEPTH 1     // weight blocks in flight ahead of the MFMAs (1 block = 16 MFMAs = 1024 cycles of cover)
-#endif
+#include "v2_common.h"
 
 namespace v2 {
-
-// All weight traffic goes through ONE buffer descriptor (4 SGPRs): per-lane part of the address is a
-// single VGPR (voff, bytes), the per-use part a scalar offset.  With plain pointers the compiler
-// hoists ~150 loop-invariant 64-bit per-lane addresses out of the time loop and spills them.
-struct WBuf {
-    i32x4 rs;
-    __device__ __forceinline__ void init(const float *p) {
-        union { const float *p; int w[2]; } u;
-        u.p = p;
-        rs = i32x4{u.w[0], u.w[1], 0x7fffffff, 0x00020000};
-    }
-    __device__ __forceinline__ float4 ld4(int voff_bytes, int soff_floats) const {
-        asm volatile("" : "+s"(soff_floats));     // keep scalar offsets out of loop-invariant hoisting (SGPR spills)
-        const f32x4 v = dn_buffer_load_f32x4(rs, voff_bytes, soff_floats * 4, 0);
-        return make_float4(v.x, v.y, v.z, v.w);
-    }
-    __device__ __forceinline__ float ld1(int voff_bytes, int soff_floats) const {
-        return dn_buffer_load_f32(rs, voff_bytes, soff_floats * 4, 0);
-    }
-};
-
-// Hardware transcendental units (v_exp_f32 / v_rcp_f32 / v_log_f32, 1 ulp) instead of the ~10-instruction
-// libm expansions: the per-lane epilogues are pure VALU time next to the MFMA stream.  Relative error
-// <= ~2e-7 * (1 + |x|), two orders below the 1e-4 parity tolerance (checked by tests/test_gpu_parity.py).
-__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
-__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
-__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
-__device__ __forceinline__ float ftanh(float x) {
-    const float xc = fminf(fmaxf(x, -15.f), 15.f);
-    return 1.0f - 2.0f * frcp(1.0f + fexp(2.0f * xc));
-}
-__device__ __forceinline__ float lrelu(float v, float s) { return fmaxf(v, v * s); }     // 0 < s < 1
-__device__ __forceinline__ float sigm(float v) { return frcp(1.0f + fexp(-v)); }
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
-__device__ __forceinline__ int xhalf(int v) { return __shfl_xor(v, 32); }
-
-template <int N>
-__device__ __forceinline__ void zero(T16 (&x)[N]) {
-#pragma unroll
-    for (int t = 0; t < N; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
-}
-
-// One (n-tile, k-tile) block of packed weights: 4 x float4 per lane = the A (or B) operands of 16 MFMAs.
-struct WBlk {
-    float4 v[4];
-};
-__device__ __forceinline__ WBlk wload(const WBuf &wp, int off, int lane) {
-    WBlk b;
-    asm volatile("" : "+s"(off));     // keep the scalar offset out of loop-invariant hoisting (SGPR spills)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) b.v[j] = wp.ld4(lane * 16 + j * 1024, off);
-    return b;
-}
-
-// out[nt] += W(nt,kt) . x[kt]     TR = false: S <- S (weights are the A operand)
-//                                 TR = true : T <- S (weights are the B operand: out = x^T W^T)
-// Weight blocks are software pipelined two deep across the whole step: `pre` is this call's first
-// block (already in flight, issued by the previous call), `next_off` the first block of whatever
-// consumes weights next; the return value is that block, in flight.
-template <int NT, int KT, bool TR>
-__device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, const T16 (&x)[KT], int lane, WBlk pre,
-                                   int next_off) {
-    constexpr int NB = NT * KT;
-#if DN_V2_DEPTH == 2
-    WBlk q0 = pre, q1, q2;
-    q1 = wload(wp, NB > 1 ? off + 1024 : next_off, lane);
-#else
-    WBlk q0 = pre, q1;
-#endif
-#pragma unroll
-    for (int b = 0; b < NB; ++b) {
-#if DN_V2_DEPTH == 2
-        if (b + 2 <= NB) q2 = wload(wp, b + 2 < NB ? off + (b + 2) * 1024 : next_off, lane);
-#else
-        q1 = wload(wp, b + 1 < NB ? off + (b + 1) * 1024 : next_off, lane);
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        const int nt = b / KT, kt = b % KT;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float4 a = q0.v[j];
-            if (!TR) {
-                out[nt] = MFMA(a.x, x[kt][4 * j + 0], out[nt]);
-                out[nt] = MFMA(a.y, x[kt][4 * j + 1], out[nt]);
-                out[nt] = MFMA(a.z, x[kt][4 * j + 2], out[nt]);
-                out[nt] = MFMA(a.w, x[kt][4 * j + 3], out[nt]);
-            } else {
-                out[nt] = MFMA(x[kt][4 * j + 0], a.x, out[nt]);
-                out[nt] = MFMA(x[kt][4 * j + 1], a.y, out[nt]);
-                out[nt] = MFMA(x[kt][4 * j + 2], a.z, out[nt]);
-                out[nt] = MFMA(x[kt][4 * j + 3], a.w, out[nt]);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        q0 = q1;
-#if DN_V2_DEPTH == 2
-        q1 = q2;
-#endif
-    }
-    return q0;
-}
-
-// x[nt][r] += v[nt*32 + feature(r, h)]   for a vector stored [NT*32]
-template <int NT>
-__device__ __forceinline__ void add_vec(T16 (&x)[NT], const WBuf &wp, int off, int voff, int lh) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 b = wp.ld4(voff + lh * 16, off + nt * 32 + 8 * a);
-            x[nt][4 * a + 0] += b.x;
-            x[nt][4 * a + 1] += b.y;
-            x[nt][4 * a + 2] += b.z;
-            x[nt][4 * a + 3] += b.w;
-        }
-}
-
-// ACT: 0 none, 1 LeakyReLU(0.01), 2 ReLU
-template <int ACT, int NT>
-__device__ __forceinline__ void finish(T16 (&x)[NT], const WBuf &wp, const V2Lin &L, int gsel, int lh) {
-    if (L.bias >= 0) add_vec<NT>(x, wp, L.bias, 0, lh);
-    if (L.gather >= 0) add_vec<NT>(x, wp, L.gather, gsel * (NT * 32 * 4), lh);
-    if (ACT != 0) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[nt][r] = ACT == 1 ? lrelu(x[nt][r], 0.01f) : fmaxf(x[nt][r], 0.f);
-    }
-}
-
-// softmax over the first G features of an S-layout row (features >= G are set to 0)
-template <int NT>
-__device__ __forceinline__ void softmax_feat(T16 (&x)[NT], int G, int lh) {
-    float mx = -INFINITY;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (nt * 32 + FR(r) + 4 * lh < G) mx = fmaxf(mx, x[nt][r]);
-    mx = fmaxf(mx, xhalf(mx));
-    float sum = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float e = (nt * 32 + FR(r) + 4 * lh < G) ? fexp(x[nt][r] - mx) : 0.f;
-            x[nt][r] = e;
-            sum += e;
-        }
-    sum += xhalf(sum);
-    const float inv = frcp(sum);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x[nt][r] = x[nt][r] * inv;
-}
-
-// attention weights of this lane's row over the 16 tile rows its half owns:
-// alpha[r] = softmax_j( mask ? LeakyReLU(s1 + s2[j]) : -9e15 ),  j = FR(r) + 4*lh
-__device__ __forceinline__ void attn_weights(T16 &alpha, float s1, const float (&s2)[16], unsigned amask, float slope) {
-    float e[16];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        e[r] = ((amask >> r) & 1u) ? lrelu(s1 + s2[r], slope) : -9e15f;
-        mx = fmaxf(mx, e[r]);
-    }
-    mx = fmaxf(mx, xhalf(mx));
-    float sum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        e[r] = fexp(e[r] - mx);
-        sum += e[r];
-    }
-    sum += xhalf(sum);
-    const float inv = frcp(sum);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) alpha[r] = e[r] * inv;
-}
-
-// Dense GAT (P heads of F features with P*F = 32 -> out_att -> BatchNorm(eval) -> tanh) on the tile.
-// x: KT input tiles (S).  out: NT tiles (S).  xch: per-wave LDS scratch of >= 32*4 floats.
-template <int KT, int NT>
-__device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WBuf &wp, const V2Gat &Gw, unsigned amask,
-                                    float slope, float *xch, int lane, WBlk pre, int next_off) {
-    const int lh = lane >> 5, lc = lane & 31;
-    // Wh for all heads, transposed: lane = head feature, register = tile row
-    T16 whT[1], sf[1];
-    zero(whT);
-    zero(sf);
-    pre = mm<1, KT, true>(whT, wp, Gw.heads, x, lane, pre, Gw.fold);
-    // s1[p] = a_src[p].Wh_row, s2[p] = a_dst[p].Wh_row through folded weights: features 0..3 / 4..7
-    pre = mm<1, KT, false>(sf, wp, Gw.fold, x, lane, pre, Gw.fold_out);
-    float s1[4];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) s1[p] = __shfl(sf[0][p], lc);          // half 0 holds features 0..3
-    __syncthreads();
-    if (lh == 1) {                                                       // half 1 holds features 4..7 = s2 of the 4 heads
-#pragma unroll
-        for (int p = 0; p < 4; ++p) xch[p * 32 + lc] = sf[0][p];
-    }
-    __syncthreads();
-    T16 x2[1];
-    zero(x2);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        float s2[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) s2[r] = xch[p * 32 + FR(r) + 4 * lh];
-        T16 alpha;
-        attn_weights(alpha, s1[p], s2, amask, slope);
-        const bool mine = (lc >> 3) == p;     // this lane's feature belongs to head p
-#pragma unroll
-        for (int r = 0; r < 16; ++r) x2[0] = MFMA(mine ? whT[0][r] : 0.f, alpha[r], x2[0]);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) x2[0][r] = x2[0][r] > 0.f ? x2[0][r] : fexp(x2[0][r]) - 1.0f;     // ELU
-    // out_att
-    T16 sf2[1];
-    zero(sf2);
-    pre = mm<1, 1, false>(sf2, wp, Gw.fold_out, x2, lane, pre, Gw.out);
-    const float t1 = __shfl(sf2[0][0], lc), t2own = __shfl(sf2[0][1], lc);
-    __syncthreads();
-    if (lh == 0) xch[lc] = t2own;
-    __syncthreads();
-    float s2o[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) s2o[r] = xch[FR(r) + 4 * lh];
-    T16 alpha;
-    attn_weights(alpha, t1, s2o, amask, slope);
-    zero(out);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {      // one output tile at a time: Wh2^T tile -> aggregation (keeps 16, not NT*16, registers live)
-        T16 wh2T[1];
-        zero(wh2T);
-        pre = mm<1, 1, true>(wh2T, wp, Gw.out + nt * 1024, x2, lane, pre, nt + 1 < NT ? Gw.out + (nt + 1) * 1024 : next_off);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], alpha[r], out[nt]);
-    }
-    // BatchNorm1d (running statistics) + tanh; padded features stay 0
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int fs = nt * 32 + 8 * a;
-            const float4 sc = wp.ld4(lh * 16, Gw.bn + fs);               // gamma / sqrt(var + eps)
-            const float4 sh = wp.ld4(lh * 16, Gw.bn + NT * 32 + fs);     // beta - mean * scale
-            const float g4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = out[nt][4 * a + i] * g4[i] + b4[i];
-                out[nt][4 * a + i] = ftanh(v);      // padded features: scale = shift = 0 -> tanh(0) = 0
-            }
-        }
-    return pre;
-}
-
-// One GRU layer.  xin: KX input tiles; h: 2 tiles (R = 64), updated in place.
-template <int KX>
-__device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBuf &wp, const V2Gru &Gw, int lane, WBlk pre,
-                                    int next_off) {
-    const int lh = lane >> 5;
-    T16 hn[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        // gates one after the other so that only one accumulator plus two 16-register results are live:
-        //   nh -> r -> t = r*(W_hn h + b_hn) -> n = tanh(W_in x + b_in + t) -> z -> h' = (1-z) n + z h
-        // weights of a gate are packed per output tile: offset of tile nt = nt * KT * 1024 floats
-        const int ox = nt * KX * 1024, oh = nt * 2 * 1024;
-        T16 acc[1], tt, ng;
-        zero(acc);
-        pre = mm<1, 2, false>(acc, wp, Gw.nh.w[0] + oh, h, lane, pre, Gw.r.w[0] + ox);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 b = wp.ld4(lh * 16, Gw.nh.bias + nt * 32 + 8 * a);
-            tt[4 * a + 0] = acc[0][4 * a + 0] + b.x; tt[4 * a + 1] = acc[0][4 * a + 1] + b.y;
-            tt[4 * a + 2] = acc[0][4 * a + 2] + b.z; tt[4 * a + 3] = acc[0][4 * a + 3] + b.w;
-        }
-        zero(acc);
-        pre = mm<1, KX, false>(acc, wp, Gw.r.w[0] + ox, xin, lane, pre, Gw.r.w[1] + oh);
-        pre = mm<1, 2, false>(acc, wp, Gw.r.w[1] + oh, h, lane, pre, Gw.ni.w[0] + ox);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 b = wp.ld4(lh * 16, Gw.r.bias + nt * 32 + 8 * a);
-            tt[4 * a + 0] *= sigm(acc[0][4 * a + 0] + b.x); tt[4 * a + 1] *= sigm(acc[0][4 * a + 1] + b.y);
-            tt[4 * a + 2] *= sigm(acc[0][4 * a + 2] + b.z); tt[4 * a + 3] *= sigm(acc[0][4 * a + 3] + b.w);
-        }
-        zero(acc);
-        pre = mm<1, KX, false>(acc, wp, Gw.ni.w[0] + ox, xin, lane, pre, Gw.z.w[0] + ox);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 b = wp.ld4(lh * 16, Gw.ni.bias + nt * 32 + 8 * a);
-            ng[4 * a + 0] = ftanh((acc[0][4 * a + 0] + b.x) + tt[4 * a + 0]); ng[4 * a + 1] = ftanh((acc[0][4 * a + 1] + b.y) + tt[4 * a + 1]);
-            ng[4 * a + 2] = ftanh((acc[0][4 * a + 2] + b.z) + tt[4 * a + 2]); ng[4 * a + 3] = ftanh((acc[0][4 * a + 3] + b.w) + tt[4 * a + 3]);
-        }
-        zero(acc);
-        pre = mm<1, KX, false>(acc, wp, Gw.z.w[0] + ox, xin, lane, pre, Gw.z.w[1] + oh);
-        pre = mm<1, 2, false>(acc, wp, Gw.z.w[1] + oh, h, lane, pre, nt == 0 ? Gw.nh.w[0] + 2 * 1024 : next_off);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 b = wp.ld4(lh * 16, Gw.z.bias + nt * 32 + 8 * a);
-            const float b4[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * a + i;
-                const float zg = sigm(acc[0][r] + b4[i]);
-                hn[nt][r] = (1.0f - zg) * ng[r] + zg * h[nt][r];
-            }
-        }
-    }
-    h[0] = hn[0];
-    h[1] = hn[1];
-    return pre;
-}
 
 // MODEL: 0 VRNN, 1 A-VRNN, 2 DAG-Net, 3 DAG-Net whose goal head runs outside this kernel (wide_head.hip: the goal of the
 // step is read from the per-sample goal state; state is per (sample, row) and written back after the last step).

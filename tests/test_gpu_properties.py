@@ -298,3 +298,33 @@ def test_wide_goal_head_agrees_with_generic_kernel_on_ragged_sdd_batch():
         assert float(d[same].max()) < 2e-4
     s2, _ = _sample_k("dagnet", m, K, T, h, batch, return_goals=True, seed=21)
     assert torch.equal(s2, s_w), "the wide path is not deterministic for a fixed seed"
+
+
+@pytest.mark.parametrize("kind,kw", [("vrnn", dict(n_layers=2)), ("avrnn", dict(n_layers=1)), ("dagnet", dict(n_layers=2))])
+@pytest.mark.parametrize("compact", [False, True])
+def test_forward_kernels_agree(kind, kw, compact):
+    """Teacher-forced pass: the register-resident kernel (forward_v2.hip) against the generic one on 41 ragged scenes, dense and
+    compact adjacency, injected and in-kernel noise; losses to 1e-5 relative, h to 2e-5."""
+    from dagnet_amd.adjacency_matrix import compute_adjs_distsim
+    a, m, _ = _model(kind, n_max=12, **kw)
+    sizes = [int(v) for v in np.random.default_rng(3).integers(1, 13, size=41)]
+    obs, gt, obs_rel, gt_rel, og, pg, sse = [t.to(DEV) for t in syn.make_batch(sizes, 10, 4, 8)]
+    N = obs.shape[1]
+    adj = compute_adjs_distsim(a, sse, obs, gt, compact=compact) if kind != "vrnn" else None
+    eps = syn.uniform_noise(8, "eps", (9, N, a.z_dim)).to(DEV)
+
+    def run(**noise):
+        if kind == "vrnn":
+            kld, nll, h = m(obs_rel, **noise)
+            return kld, nll, kld * 0, h
+        if kind == "avrnn":
+            kld, nll, h = m(obs_rel, adj, seq_start_end=sse, **noise)
+            return kld, nll, kld * 0, h
+        return m(obs, obs_rel, og.to(torch.int32), sse, adj, **noise)
+    for noise in (dict(eps=eps), dict(seed=5)):
+        fast = run(**noise)
+        with generic_kernel():
+            slow = run(**noise)
+        for f, s, what in zip(fast[:3], slow[:3], ("KLD", "NLL", "CE")):
+            assert abs(float(f) - float(s)) <= 1e-5 * max(1.0, abs(float(s))), what
+        assert float((fast[3] - slow[3]).abs().max()) < 2e-5

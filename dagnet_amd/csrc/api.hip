@@ -997,8 +997,20 @@ extern "C" void dagnet_plan_destroy(dagnet_plan *p) {
     delete p;
 }
 
+extern "C" int dagnet_plan_kernel(const dagnet_plan *p);
 extern "C" int dagnet_plan_info(const dagnet_plan *p, int32_t *tile_rows, int32_t *n_tiles, int64_t *lds_bytes) {
     if (!p) return fail(DAGNET_ERR_INVALID, "null plan");
+    // geometry of the kernel dagnet_sample() will run on this plan (dagnet_plan_kernel)
+    const int kind = dagnet_plan_kernel(p);
+    if (kind == 2 || kind == 3) {       // register-resident: one wave per tile of <= 32 rows; static LDS of the wave
+        const dagnet_model *m = p->owner;
+        const int64_t stash = m->dims.model == DAGNET_MODEL_DAGNET && kind == 2 ? (int64_t)m->dims.L * 32 * 64
+                              : (m->dims.L == 2 ? 32 * 64 : 1);
+        if (tile_rows) *tile_rows = 32;
+        if (n_tiles) *n_tiles = p->n_tiles2;
+        if (lds_bytes) *lds_bytes = (stash + 32 * 4 + 64) * 4;
+        return DAGNET_OK;
+    }
     if (tile_rows) *tile_rows = p->M;
     if (n_tiles) *n_tiles = p->n_tiles;
     if (lds_bytes) *lds_bytes = (int64_t)p->lds.total * 4;

@@ -84,10 +84,11 @@ void dagnet_model_destroy(dagnet_model *m);
 int dagnet_plan_create(const dagnet_model *m, const int32_t *h_scene_ptr, int32_t n_scenes,
                        int32_t n_samples, dagnet_plan **out);
 void dagnet_plan_destroy(dagnet_plan *p);
-/* rows per workgroup tile / number of tiles chosen for the plan (for reporting) */
+/* rows per tile / number of tiles / LDS bytes per workgroup of the kernel dagnet_sample() runs on this plan (reporting) */
 int dagnet_plan_info(const dagnet_plan *p, int32_t *tile_rows, int32_t *n_tiles, int64_t *lds_bytes);
-/* which sample() kernel the plan dispatches to: 2 = register-resident (rollout_v2.hip), 0 = generic LDS-tiled,
- * 1 = generic with goal-width buffers in global scratch (g_dim too large for the LDS); -1 = tables-only plan */
+/* which sample() kernel the plan dispatches to: 2 = register-resident (rollout_v2.hip), 3 = wide goal head (batched GEMMs,
+ * wide_head.hip + gemm_f32.hip) + register-resident step kernel, 0 = generic LDS-tiled, 1 = generic with goal-width
+ * buffers in global scratch (g_dim too large for the LDS); -1 = tables-only plan */
 int dagnet_plan_kernel(const dagnet_plan *p);
 
 /* Replaces: K calls of DAGNet.sample / AVRNN.sample / VRNN.sample

@@ -219,7 +219,7 @@ def bench_train(opt, wl, rank, world, dev, dist):
                      "kernel": "layer-by-layer operators (gemm_nt_kernel + train_ops.hip), launch-bound at this batch"},
         "loss": float(loss.detach()),
     }
-    if not opt.no_cpu_baseline:
+    if not opt.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_train_baseline(wl)
     print(json.dumps(line), flush=True)
 
@@ -265,7 +265,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DAGNET_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -368,7 +368,7 @@ def main():
             "forward_obs_ms": fwd_ms,
             "ade": float(tot[0] / (tot[2] * T)), "fde": float(tot[1] / tot[2]),
         }
-        if not opt.no_cpu_baseline:
+        if not opt.no_cpu_baseline and world == 1:         # the CPU leg runs on rank 0 of the single-GPU run only
             line["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -19,7 +19,7 @@ from ._capi import DagnetHipError, _check, _stream
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
 OP_EXPORTS = (
-    "dagnet_op_gemm", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_act_bwd", "dagnet_op_copy2d",
+    "dagnet_op_gemm", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
     "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
@@ -39,6 +39,8 @@ def _lib():
         lib.dagnet_op_gemm_tn_workspace.argtypes = [i32, i32, i32]
         lib.dagnet_op_gemm_tn_workspace.restype = i64
         lib.dagnet_op_gemm_tn.argtypes = [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp, i32, vp]
+        lib.dagnet_op_gemm_tn_partial.argtypes = [vp, i64, vp, i64, vp, i32, i32, i32, i32, vp, i32, vp]
+        lib.dagnet_op_gemm_tn_finish.argtypes = [vp, vp, i64, vp, i32, i32, i32, i32, vp]
         lib.dagnet_op_act_bwd.argtypes = [i64, i32, vp, i64, vp, i64, vp, i64, i32, f32, vp]
         lib.dagnet_op_copy2d.argtypes = [i64, i32, vp, i64, vp, i64, i32, vp]
         lib.dagnet_op_onehot_grad.argtypes = [i64, i32, i32, vp, i64, vp, vp, i64, vp, i32, vp]
@@ -143,6 +145,52 @@ def copy2d(src, dst, accumulate=False):
     _check(_lib().dagnet_op_copy2d(src.shape[0], src.shape[1], s, lds, d, ldd, int(accumulate), _stream(src.device)))
 
 
+class DeferredGrads:
+    """Weight / bias gradients of sink parameters (training.attach_grad_arena) are summed over the time steps as split
+    partial sums (dagnet_op_gemm_tn_partial) and reduced ONCE at the end of the backward pass (dagnet_op_gemm_tn_finish,
+    queued as an autograd engine callback) instead of once per layer and time step."""
+
+    def __init__(self):
+        self.slots = {}
+        self.pending = False
+
+    def add(self, key, A, B, dst, gidx=None, bias_dst=None):
+        """dst[N,K] (a view of the gradient arena) += A[M,N]^T B[M,K]  (B None: one-hot from gidx); bias_dst[N] += colsum(A)."""
+        lib = _lib()
+        M, N = A.shape
+        K = dst.shape[1]
+        key = key + (M, N, K)
+        slot = self.slots.get(key)
+        if slot is None:
+            part = torch.empty(int(lib.dagnet_op_gemm_tn_workspace(M, N, K)), dtype=torch.float32, device=A.device)
+            slot = self.slots[key] = dict(part=part, dst=dst, bias=bias_dst, M=M, N=N, K=K, first=True, dirty=False)
+        (a, lda) = _m(A, "A")
+        b, ldb = (None, 0) if B is None else _m(B, "B")
+        _check(lib.dagnet_op_gemm_tn_partial(a, lda, b, ldb, _p(gidx), int(bias_dst is not None), M, N, K, _p(slot["part"]),
+                                             int(slot["first"]), _stream(A.device)))
+        slot["first"] = False
+        slot["dirty"] = True
+        if not self.pending:
+            self.pending = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+
+    def finish(self):
+        lib = _lib()
+        for slot in self.slots.values():
+            if not slot["dirty"]:
+                continue
+            dst = slot["dst"]
+            (c, ldc) = _m(dst, "gradient")
+            _check(lib.dagnet_op_gemm_tn_finish(_p(slot["part"]), c, ldc, _p(slot["bias"]), slot["M"], slot["N"], slot["K"], 1,
+                                                _stream(dst.device)))
+            slot["first"], slot["dirty"] = True, False
+        self.pending = False
+
+
+def _defer(p: torch.Tensor):
+    return getattr(p, "_hip_defer", None)
+
+
 def _sink(p: torch.Tensor):
     """Gradient arena view of a parameter (training.attach_grad_arena): the backward kernels then accumulate straight into
     p.grad and hand autograd None, which saves one zero-fill and one torch add per parameter use and time step."""
@@ -208,9 +256,16 @@ class LinearFn(torch.autograd.Function):
             fused_b = None
             if has_b and ctx.needs_input_grad[1] and (bsink is not None) == acc:
                 fused_b = bsink if acc else torch.empty(N, dtype=torch.float32, device=y.device)
+            defer = _defer(ctx.W_param) if acc else None
             for s_, (x, c0) in enumerate(zip(xs, cols)):
-                gemm_tn(dpre, x, dW[:, c0:c0 + x.shape[1]], accumulate=acc, dbias=fused_b if s_ == 0 else None)
-            if gidx is not None:
+                dst = dW[:, c0:c0 + x.shape[1]]
+                if defer is not None:
+                    defer.add((id(ctx.W_param), c0), dpre, x, dst, bias_dst=fused_b if s_ == 0 else None)
+                else:
+                    gemm_tn(dpre, x, dst, accumulate=acc, dbias=fused_b if s_ == 0 else None)
+            if gidx is not None and defer is not None:
+                defer.add((id(ctx.W_param), gcol), dpre, None, dW[:, gcol:gcol + gdim], gidx=gidx)
+            elif gidx is not None:
                 (dp, ldp) = _m(dpre)
                 ws = _ws(y.device, _lib().dagnet_op_gemm_tn_workspace(M, N, gdim))
                 _check(_lib().dagnet_op_onehot_grad(M, N, gdim, dp, ldp, _p(gidx), C.c_void_p(dW.data_ptr() + 4 * gcol), Ktot, _p(ws),
@@ -264,7 +319,9 @@ class MatmulFn(torch.autograd.Function):
             gemm(dy, W, dx)                       # dy [M,N] . W[K,N]^T
         if ctx.needs_input_grad[1]:
             sink = _sink(ctx.W_param)
-            if sink is not None:
+            if sink is not None and _defer(ctx.W_param) is not None:
+                _defer(ctx.W_param).add((id(ctx.W_param), 0), x, dy, sink)
+            elif sink is not None:
                 gemm_tn(x, dy, sink, accumulate=True)
             else:
                 dW = torch.empty_like(W)

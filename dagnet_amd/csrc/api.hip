@@ -1276,6 +1276,9 @@ extern "C" hipError_t dn_gemm_tn(const float *A, int64_t lda, const float *B, in
                                  float *part, int accumulate, hipStream_t st);
 extern "C" hipError_t dn_gemm_tn_idx(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, float *C, int64_t ldc,
                                      float *dbias, int M, int N, int K, float *part, int accumulate, hipStream_t st);
+extern "C" hipError_t dn_gemm_tn_staged(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, float *C,
+                                        int64_t ldc, float *dbias, int want_bias, int M, int N, int K, float *part, int accumulate,
+                                        int stages, int part_accumulate, hipStream_t st);
 extern "C" hipError_t dn_t_act_bwd(int64_t, int, const float *, int64_t, const float *, int64_t, float *, int64_t, int, float, hipStream_t);
 extern "C" hipError_t dn_t_copy2d(int64_t, int, const float *, int64_t, float *, int64_t, int, hipStream_t);
 extern "C" hipError_t dn_t_softmax_fwd(int64_t, int, const float *, int64_t, float *, int64_t, hipStream_t);
@@ -1337,6 +1340,27 @@ extern "C" int dagnet_op_gemm_tn(const float *A, int64_t lda, const float *B, in
     OP_NEED(A && B && C && workspace, "null operand");
     OP_NEED(lda >= N && ldb >= K && ldc >= K, "row stride smaller than the row");
     HIP_TRY(dn_gemm_tn_idx(A, lda, B, ldb, nullptr, C, ldc, dbias, M, N, K, workspace, accumulate, OP_ST));
+    return DAGNET_OK;
+}
+// Weight gradient of one layer accumulated over many calls (time steps) with ONE final reduction: stage 1 adds this call's
+// split partial sums to `part` (first != 0: overwrites them), dagnet_op_gemm_tn_finish reduces them into C / dbias.
+// B = NULL with bidx: one-hot second operand (dagnet_op_onehot_grad).  part: dagnet_op_gemm_tn_workspace(M, N, K) floats,
+// owned by the caller for the whole accumulation; M, N, K must be the same in every call.
+extern "C" int dagnet_op_gemm_tn_partial(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, int32_t want_bias,
+                                         int32_t M, int32_t N, int32_t K, float *part, int32_t first, void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    if (N == 0 || K == 0) return DAGNET_OK;
+    OP_NEED(A && (B || bidx) && part, "null operand");
+    HIP_TRY(dn_gemm_tn_staged(A, lda, B, ldb, bidx, nullptr, 0, nullptr, want_bias, M, N, K, part, 0, 1, first ? 0 : 1, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_gemm_tn_finish(const float *part, float *C, int64_t ldc, float *dbias, int32_t M, int32_t N, int32_t K,
+                                        int32_t accumulate, void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    if (N == 0 || K == 0) return DAGNET_OK;
+    OP_NEED(part && C && ldc >= K, "bad argument");
+    HIP_TRY(dn_gemm_tn_staged(nullptr, 0, nullptr, 0, nullptr, C, ldc, dbias, dbias != nullptr, M, N, K, const_cast<float *>(part),
+                              accumulate, 2, 0, OP_ST));
     return DAGNET_OK;
 }
 extern "C" int dagnet_op_act_bwd(int64_t M, int32_t N, const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp,

@@ -183,6 +183,7 @@ struct TnArgs {
     int rows_per_split;               // multiple of 32
     const int32_t *bidx;              // not null: B is one-hot, B[m][k] = (bidx[m] == k)   (gradients of one-hot inputs)
     float *bias_part;                 // not null: [splits][N] column sums of A over this split's rows (bias gradient)
+    int part_accumulate;              // add to the partial sums already in C / bias_part (several calls, one final reduction)
 };
 
 // C_split[n][k] = sum over this split's rows m of A[m][n] * B[m][k].  Workgroup tile 64 x 64 (2x2 waves, 1 tile each),
@@ -261,7 +262,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
             float t = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) t += sA[0][r][tid];
-            p.bias_part[(int64_t)blockIdx.y * p.N + n0 + tid] = t;
+            float *bp = p.bias_part + (int64_t)blockIdx.y * p.N + n0 + tid;
+            *bp = p.part_accumulate ? *bp + t : t;
         }
     }
     float *C = p.C + (int64_t)blockIdx.y * p.N * p.ldc;
@@ -269,7 +271,10 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = n0 + wm * 32 + 4 * lh + (r & 3) + 8 * (r >> 2);
-        if (row < p.N && col < p.K) C[(int64_t)row * p.ldc + col] = acc[r];
+        if (row < p.N && col < p.K) {
+            float *dst = C + (int64_t)row * p.ldc + col;
+            *dst = p.part_accumulate ? *dst + acc[r] : acc[r];
+        }
     }
 }
 
@@ -354,26 +359,39 @@ extern "C" int64_t dn_gemm_tn_splits(int M, int N, int K) {
     return s < 1 ? 1 : (s > 512 ? 512 : s);
 }
 extern "C" int64_t dn_gemm_tn_workspace(int M, int N, int K) { return dn_gemm_tn_splits(M, N, K) * ((int64_t)N * K + N); }
-// dbias (nullable): [N] (+)= column sums of A, computed by the same pass over A (the bias gradient of the layer)
-extern "C" hipError_t dn_gemm_tn_idx(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, float *C, int64_t ldc,
-                                     float *dbias, int M, int N, int K, float *part, int accumulate, hipStream_t st) {
+// dbias (nullable): [N] (+)= column sums of A, computed by the same pass over A (the bias gradient of the layer).
+// stages: 1 = split partial sums only (part_accumulate: add to the partials of earlier calls with the same M, N, K),
+//         2 = final reduction of the partials into C / dbias only, 3 = both.
+extern "C" hipError_t dn_gemm_tn_staged(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, float *C,
+                                        int64_t ldc, float *dbias, int want_bias, int M, int N, int K, float *part, int accumulate,
+                                        int stages, int part_accumulate, hipStream_t st) {
     if (N <= 0 || K <= 0) return hipSuccess;
     const int splits = (int)dn_gemm_tn_splits(M, N, K);
     int rows = (M + splits - 1) / splits;
     rows = (rows + 31) & ~31;
     if (rows < 32) rows = 32;
-    float *bias_part = dbias ? part + (int64_t)splits * N * K : nullptr;
-    gemm::TnArgs a{A, lda, B, ldb, part, K, M, N, K, rows, bidx, bias_part};
-    const int blocks = ((N + 63) / 64) * ((K + 63) / 64);
-    hipLaunchKernelGGL(gemm::gemm_tn_kernel, dim3(blocks, splits), dim3(256), 0, st, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    const int64_t n = (int64_t)N * K;
-    hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, splits, N, K, C, ldc, accumulate);
-    if (dbias)
-        hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, bias_part, splits, 1, N, dbias,
-                           (int64_t)N, accumulate);
+    float *bias_part = want_bias ? part + (int64_t)splits * N * K : nullptr;
+    if (stages & 1) {
+        gemm::TnArgs a{A, lda, B, ldb, part, K, M, N, K, rows, bidx, bias_part, part_accumulate};
+        const int blocks = ((N + 63) / 64) * ((K + 63) / 64);
+        hipLaunchKernelGGL(gemm::gemm_tn_kernel, dim3(blocks, splits), dim3(256), 0, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    if (stages & 2) {
+        const int64_t n = (int64_t)N * K;
+        hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, splits, N, K, C, ldc,
+                           accumulate);
+        if (want_bias && dbias)
+            hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, bias_part, splits, 1, N,
+                               dbias, (int64_t)N, accumulate);
+    }
     return hipGetLastError();
+}
+
+extern "C" hipError_t dn_gemm_tn_idx(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, float *C, int64_t ldc,
+                                     float *dbias, int M, int N, int K, float *part, int accumulate, hipStream_t st) {
+    return dn_gemm_tn_staged(A, lda, B, ldb, bidx, C, ldc, dbias, dbias != nullptr, M, N, K, part, accumulate, 3, 0, st);
 }
 
 extern "C" hipError_t dn_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, int M, int N, int K,

@@ -42,11 +42,13 @@ def attach_grad_arena(model, optimizer=None) -> torch.Tensor:
     supported for sink parameters (they report None)."""
     params = [p for p in model.parameters() if p.requires_grad]
     arena = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
+    defer = _ops.DeferredGrads()              # partial sums over the time steps, one reduction per backward pass
     off = 0
     for p in params:
         n = p.numel()
         p.grad = arena[off:off + n].view_as(p)
         p._hip_sink = True
+        p._hip_defer = defer
         off += n
     model._hip_grad_arena = arena
     if optimizer is not None:

@@ -197,6 +197,14 @@ int dagnet_op_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int
 int64_t dagnet_op_gemm_tn_workspace(int32_t M, int32_t N, int32_t K);
 int dagnet_op_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float *dbias, int32_t M,
                       int32_t N, int32_t K, float *workspace, int32_t accumulate, void *stream);
+/* The same product accumulated over many calls (the time steps of one backward pass) with ONE final reduction: _partial adds
+ * this call's split partial sums to `part` (first != 0 overwrites), _finish reduces them into C (+)= and dbias (+)=.
+ * B = NULL with bidx != NULL: one-hot second operand generated from the indices.  M, N, K must not change between calls;
+ * part: dagnet_op_gemm_tn_workspace(M, N, K) floats owned by the caller for the whole accumulation. */
+int dagnet_op_gemm_tn_partial(const float *A, int64_t lda, const float *B, int64_t ldb, const int32_t *bidx, int32_t want_bias,
+                              int32_t M, int32_t N, int32_t K, float *part, int32_t first, void *stream);
+int dagnet_op_gemm_tn_finish(const float *part, float *C, int64_t ldc, float *dbias, int32_t M, int32_t N, int32_t K,
+                             int32_t accumulate, void *stream);
 /* dP = dY * act'(.) through the saved layer output Y (backward of LeakyReLU / ReLU / tanh). */
 int dagnet_op_act_bwd(int64_t M, int32_t N, const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp,
                       int32_t act, float slope, void *stream);

@@ -51,7 +51,15 @@ struct WideStep {                     // wide_head.hip
     const int32_t *force_goals;
     uint64_t seed;
     int32_t *out_goals;
+    const float *ext_pos;
+    const int32_t *ext_goal_prev;
+    const int32_t *ext_goal_t;
+    const float *ext_adj;
+    int64_t ext_adj_ld;
+    const int64_t *ext_adj_off;
+    float *ce_acc;
 };
+extern "C" hipError_t dn_wide_ce_finish(int64_t rows, const float *ce_acc, double *loss_part, hipStream_t st);
 extern "C" hipError_t dn_wide_init_state(int N, int K, int L, int R, int G, const float *h0, const float *x0, const int32_t *g0,
                                          float *h, float *pos, int32_t *goal, hipStream_t st);
 extern "C" hipError_t dn_wide_goal_head(const WideStep *sp, hipStream_t st);
@@ -619,7 +627,7 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
     }
     W.prior2 = v2_linear(pk, "prior.2", H, H, {{0, H}});
     W.prior_ml = v2_pair(pk, "prior_mean", "prior_logvar", Z, H);
-    if (!ext) {     // teacher-forced pass (forward_v2.hip)
+    {               // teacher-forced pass (forward_v2.hip)
         if (dag) W.enc0 = v2_linear(pk, "enc.0", H, H + G + R, {{0, H}, {H + G, R}}, H, G);
         else W.enc0 = v2_linear(pk, "enc.0", H, H + R, {{0, H}, {H, R}});
         W.enc2 = v2_linear(pk, "enc.2", H, H, {{0, H}});
@@ -1152,6 +1160,48 @@ extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32
     if (m->dims.model != DAGNET_MODEL_VRNN) {
         const int rc = set_adj(P, p, d_adj, adj_dense_ld);
         if (rc) return rc;
+    }
+    if (m->wide && p->wide && !getenv("DAGNET_FORCE_GENERIC")) {
+        // g_dim in the hundreds: per step the goal head layer by layer over all N rows (wide_head.hip, ending in the CE term),
+        // then one step of the register-resident teacher-forced kernel (model 3).  h_out doubles as the hidden state.
+        const DnDims &D = m->dims;
+        const int64_t N = p->N;
+        HIP_TRY(hipMemsetAsync(d_h_out, 0, sizeof(float) * D.L * N * D.R, st));
+        HIP_TRY(hipMemsetAsync(p->d_loss_part, 0, sizeof(double) * 3 * p->n_tiles2, st));
+        float *ce_acc = p->wb.pos;           // the positions state is unused in the teacher-forced pass ([rows][2] >= [rows])
+        HIP_TRY(hipMemsetAsync(ce_acc, 0, sizeof(float) * N, st));
+        WideStep ws;
+        memset(&ws, 0, sizeof(ws));
+        ws.wp = m->d_wp; ws.w = m->ww; ws.b = p->wb;
+        ws.b.h = d_h_out;
+        ws.scene_ptr = p->d_scene_ptr; ws.row_scene = p->d_row_scene; ws.off_compact = p->d_off_compact; ws.compact = 0;
+        ws.N = p->N; ws.K = 1; ws.S = p->S; ws.T = T;
+        ws.D = D.D; ws.R = D.R; ws.H = D.H; ws.G = D.G; ws.L = D.L; ws.P = D.P; ws.F = D.F;
+        ws.adj_type = D.adj_type; ws.top_k = D.knn_k; ws.sigma = D.sigma; ws.alpha = D.alpha;
+        ws.ext_adj_ld = P.r.adj_ld; ws.ext_adj_off = P.r.adj_off; ws.ce_acc = ce_acc;
+        V2Run r;
+        memset(&r, 0, sizeof(r));
+        r.wp = m->d_wp;
+        r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
+        r.S = p->S; r.N = p->N; r.K = 1; r.T = T; r.n_tiles = p->n_tiles2;
+        r.G = D.G; r.D = D.D; r.adj_type = D.adj_type; r.alpha = D.alpha; r.sigma = D.sigma;
+        r.eps = d_eps; r.seed = seed; r.h_out = d_h_out;
+        r.traj = d_traj; r.traj_rel = d_traj_rel; r.goals = d_goals;
+        r.adj = P.r.adj; r.adj_ld = P.r.adj_ld; r.adj_tstride = P.r.adj_tstride; r.adj_off = P.r.adj_off;
+        r.loss_part = p->d_loss_part;
+        for (int t = 1; t < T; ++t) {
+            ws.t = t;
+            ws.ext_pos = d_traj + (int64_t)t * N * 2;
+            ws.ext_goal_prev = d_goals + (int64_t)(t - 1) * N;
+            ws.ext_goal_t = d_goals + (int64_t)t * N;
+            ws.ext_adj = P.r.adj + (int64_t)t * P.r.adj_tstride;
+            HIP_TRY(dn_wide_goal_head(&ws, st));
+            r.t_begin = t; r.t_end = t + 1;
+            HIP_TRY(dn_launch_forward_v2(3, D.L, D.Z, m->d_w2, &r, st));
+        }
+        HIP_TRY(dn_wide_ce_finish(N, ce_acc, p->d_loss_part, st));
+        HIP_TRY(dn_launch_loss_finalize(p->n_tiles2, p->N, p->d_loss_part, d_losses, st));
+        return DAGNET_OK;
     }
     if (m->v2 && p->n_tiles2 > 0 && !getenv("DAGNET_FORCE_GENERIC")) {
         // register-resident teacher-forced pass (forward_v2.hip); GAT consumes only the adjacency's support

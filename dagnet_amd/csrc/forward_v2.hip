@@ -24,8 +24,11 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
     const int lane = threadIdx.x, lc = lane & 31;
     WBuf wp;
     wp.init(R.wp);
-    constexpr bool DAG = MODEL == 2, GRAPH = MODEL != 0;
+    // MODEL 3: DAG-Net whose goal head (and its CE term) runs outside (wide_head.hip); steps [t_begin, t_end) per launch,
+    // hidden state read from / written back to h_out, loss partials accumulated over the launches
+    constexpr bool DAG = MODEL >= 2, HEAD = MODEL == 2, EXT = MODEL == 3, GRAPH = MODEL != 0;
     constexpr int GT = 3;
+    constexpr int DT = EXT ? 2 : 1;
     constexpr int MLT = ZD == 32 ? 2 : 1;
 
     // ---- rows of this wave (K = 1: unit = scene)
@@ -47,13 +50,28 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
     T16 h[NL][2];
 #pragma unroll
     for (int l = 0; l < NL; ++l) zero(h[l]);
+    if constexpr (EXT) {
+        const int lh0 = lane >> 5;
+        if (live) {
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const float4 v = *reinterpret_cast<const float4 *>(R.h_out + ((int64_t)l * NK + grow) * 64 + nt * 32 + 8 * a + 4 * lh0);
+                        h[l][nt][4 * a] = v.x; h[l][nt][4 * a + 1] = v.y; h[l][nt][4 * a + 2] = v.z; h[l][nt][4 * a + 3] = v.w;
+                    }
+        }
+    }
     double kld_acc = 0.0, nll_acc = 0.0, ce_acc = 0.0;
     unsigned amask = 0;
 
-    const int first_off = DAG ? W.dec_goal0.w[0] : W.phi_x2.w[0];
+    const int first_off = HEAD ? W.dec_goal0.w[0] : W.phi_x2.w[0];
+    const int t_begin = EXT ? R.t_begin : 1, t_end = EXT ? R.t_end : R.T;
     WBlk pre = wload(wp, first_off, lane);
     const int lane0 = lane, s00 = s0, n0 = n;
-    for (int t = 1; t < R.T; ++t) {
+    for (int t = t_begin; t < t_end; ++t) {
         int lane = lane0, s0 = s00, n = n0;
         asm volatile("" : "+v"(lane), "+v"(s0), "+v"(n));
         const int lh = lane >> 5, lc = lane & 31;
@@ -74,28 +92,32 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
             amask = mk;
         }
         int gt = 0;
-        T16 d[1];
+        T16 d[DT];
+        auto build_disposition = [&]() {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int f = dt * 32 + FR(r) + 4 * lh, j = f >> 1;
+                    const float pv = pos[min(s0 + j, 31) * 2 + (f & 1)];
+                    d[dt][r] = ((f < R.D) & (j < n)) ? pv : 0.f;
+                }
+        };
         if constexpr (DAG) {
             const float2 pa = live ? *reinterpret_cast<const float2 *>(R.traj + trow * 2) : make_float2(0.f, 0.f);
             __syncthreads();
             if (lh == 0) { pos[lc * 2] = pa.x; pos[lc * 2 + 1] = pa.y; }
             __syncthreads();
-            const int gprev = live ? min(max(R.goals[trow - NK], 0), R.G - 1) : 0;
             gt = live ? min(max(R.goals[trow], 0), R.G - 1) : 0;
+        }
+        if constexpr (HEAD) {
+            const int gprev = live ? min(max(R.goals[trow - NK], 0), R.G - 1) : 0;
             if constexpr (NL == 2) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) stash[((2 + nt) * 16 + r) * 64 + lane] = h[0][nt][r];
             }
-            auto build_disposition = [&]() {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int f = FR(r) + 4 * lh, j = f >> 1;
-                    const float pv = pos[min(s0 + j, 31) * 2 + (f & 1)];
-                    d[0][r] = ((f < R.D) & (j < n)) ? pv : 0.f;
-                }
-            };
             build_disposition();
             // ---------------------------------------------------------------- goal head (teacher forced: g_{t-1} in, CE on g_t)
             T16 tg[2];
@@ -229,13 +251,8 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
         finish<1, 2>(pz, wp, W.phi_z2, 0, lh);
         zero(ta);
         if constexpr (DAG) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int f = FR(r) + 4 * lh, j = f >> 1;
-                const float pv = pos[min(s0 + j, 31) * 2 + (f & 1)];
-                d[0][r] = ((f < R.D) & (j < n)) ? pv : 0.f;
-            }
-            pre = mm<2, 1, false>(ta, wp, W.dec0.w[0], d, lane, pre, W.dec0.w[1]);
+            build_disposition();
+            pre = mm<2, DT, false>(ta, wp, W.dec0.w[0], d, lane, pre, W.dec0.w[1]);
             pre = mm<2, 2, false>(ta, wp, W.dec0.w[1], pz, lane, pre, W.dec0.w[2]);
             pre = mm<2, 2, false>(ta, wp, W.dec0.w[2], h[NL - 1], lane, pre, W.dec2.w[0]);
         } else {
@@ -272,7 +289,7 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
         // -------------------------------------------------------------------- GRU
         T16 xin[4];
         xin[0] = px[0]; xin[1] = px[1]; xin[2] = pz[0]; xin[3] = pz[1];
-        if constexpr (DAG && NL == 2) {
+        if constexpr (HEAD && NL == 2) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -320,9 +337,9 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
     const bool count = live && lh == 0;
     const double k = wave_sum_d(count ? kld_acc : 0.0), nl = wave_sum_d(count ? nll_acc : 0.0), c = wave_sum_d(count ? ce_acc : 0.0);
     if (lane == 0) {
-        R.loss_part[(int64_t)blockIdx.x * 3 + 0] = k;
-        R.loss_part[(int64_t)blockIdx.x * 3 + 1] = nl;
-        R.loss_part[(int64_t)blockIdx.x * 3 + 2] = c;
+        double *lp = R.loss_part + (int64_t)blockIdx.x * 3;
+        if (EXT) { lp[0] += k; lp[1] += nl; }       // one launch per step: accumulate (zeroed by the host; CE comes from outside)
+        else { lp[0] = k; lp[1] = nl; lp[2] = c; }
     }
 }
 
@@ -334,7 +351,7 @@ static hipError_t launch_fwd(const V2Weights *d_w, const V2Run &r, hipStream_t s
     return hipGetLastError();
 }
 
-#define V2F_INSTANCES V2_CASE(2, 2, 32) V2_CASE(1, 1, 32) V2_CASE(0, 2, 32) V2_CASE(1, 1, 16) V2_CASE(0, 2, 16) V2_CASE(1, 2, 32)
+#define V2F_INSTANCES V2_CASE(2, 2, 32) V2_CASE(1, 1, 32) V2_CASE(0, 2, 32) V2_CASE(1, 1, 16) V2_CASE(0, 2, 16) V2_CASE(1, 2, 32) V2_CASE(3, 2, 32)
 
 extern "C" hipError_t dn_launch_forward_v2(int model, int n_layers, int z_dim, const V2Weights *d_w, const V2Run *r, hipStream_t st) {
 #define V2_CASE(M, L, Z) \

@@ -103,7 +103,7 @@ __global__ void softmax_kernel(int64_t rows, int G, int64_t ld, float *__restric
 // and the folded logits of the out head: S2[i] = [X2_i . (W_out a_src), X2_i . (W_out a_dst)]
 template <int P, int F>
 __global__ void attn_heads_kernel(int N, int K, const int32_t *__restrict__ scene_ptr, const int32_t *__restrict__ row_scene,
-                                  const int64_t *__restrict__ off_compact, int64_t compact, const float *__restrict__ adj,
+                                  const int64_t *__restrict__ off_compact, int64_t compact, int64_t adj_ld, const float *__restrict__ adj,
                                   const float *__restrict__ HS, int64_t hs_ld, const float *__restrict__ fold_out, float alpha,
                                   float *__restrict__ X2, float *__restrict__ S2) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -114,7 +114,8 @@ __global__ void attn_heads_kernel(int N, int K, const int32_t *__restrict__ scen
     const int s = row_scene[g];
     const int b = scene_ptr[s], n = scene_ptr[s + 1] - b;
     const int64_t r0 = (int64_t)k * N + b;
-    const float *arow = adj + (int64_t)k * compact + off_compact[s] + (int64_t)(g - b) * n;
+    // adjacency block of the scene: compact (row stride n) or dense [N,N] (row stride adj_ld; off_compact then holds b*N+b)
+    const float *arow = adj + (int64_t)k * compact + off_compact[s] + (int64_t)(g - b) * (adj_ld ? adj_ld : (int64_t)n);
     const float ssrc = HS[r * hs_ld + P * F + p];
     float mx = -INFINITY;
     for (int j = 0; j < n; ++j)
@@ -159,7 +160,7 @@ __global__ void attn_heads_kernel(int N, int K, const int32_t *__restrict__ scen
 // out head of graph_goals (concat=False) + eval BatchNorm + tanh (gat_model.py:18-22), one workgroup per
 // (sample, scene):  out_i = tanh(scale * sum_j a_ij B_j + shift), written to columns [dst_col0, dst_col0 + G) of A1
 __global__ __launch_bounds__(256) void attn_out_kernel(int N, int S, const int32_t *__restrict__ scene_ptr,
-                                                       const int64_t *__restrict__ off_compact, int64_t compact,
+                                                       const int64_t *__restrict__ off_compact, int64_t compact, int64_t adj_ld,
                                                        const float *__restrict__ adj, const float *__restrict__ S2, float alpha,
                                                        const float *__restrict__ B, int64_t ldb, int G,
                                                        const float *__restrict__ bn, float *__restrict__ out, int64_t ldo) {
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_out_kernel(int N, int S, const int32
     for (int e = tid; e < n * n; e += 256) {
         const int i = e / n, j = e - i * n;
         const float v = S2[(r0 + i) * 2] + S2[(r0 + j) * 2 + 1];
-        att[i][j] = ablk[e] > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
+        att[i][j] = ablk[(int64_t)i * (adj_ld ? adj_ld : (int64_t)n) + j] > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
     }
     __syncthreads();
     if (tid < n) {
@@ -255,6 +256,39 @@ __global__ void draw_kernel(int N, int K, int T, int t, int G, const float *__re
     }
 }
 
+// teacher-forced pass: ce_acc[r] -= softmax(LG[r])[goal_t[r]]   (models/dagnet/model.py:162), one wave per row
+__global__ void ce_kernel(int64_t rows, int G, const float *__restrict__ LG, int64_t ld, const int32_t *__restrict__ goal_t,
+                          float *__restrict__ ce_acc) {
+    const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float *p = LG + r * ld;
+    float mx = -INFINITY;
+    for (int c = lane; c < G; c += 64) mx = fmaxf(mx, p[c]);
+    mx = wave_max(mx);
+    float s = 0.f;
+    for (int c = lane; c < G; c += 64) s += expf(p[c] - mx);
+    s = wave_sum(s);
+    if (lane == 0) {
+        const int g = min(max(goal_t[r], 0), G - 1);
+        ce_acc[r] -= expf(p[g] - mx) / s;
+    }
+}
+
+// loss_part[2] += sum_r ce_acc[r]  (fp64, fixed order, one workgroup)
+__global__ __launch_bounds__(1024) void ce_finish_kernel(int64_t rows, const float *__restrict__ ce_acc, double *__restrict__ loss_part) {
+    __shared__ double red[1024];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < rows; i += 1024) s += (double)ce_acc[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss_part[2] += red[0];
+}
+
 }   // namespace wide
 
 struct WideStep {
@@ -273,6 +307,15 @@ struct WideStep {
     const int32_t *force_goals;
     uint64_t seed;
     int32_t *out_goals;
+    // teacher-forced pass (ce_acc != NULL): K = 1, positions / previous goals / goals of the step and the adjacency come
+    // from the batch; the head ends in the CE term instead of a draw
+    const float *ext_pos;             // [N,2] positions of the step
+    const int32_t *ext_goal_prev;     // [N]
+    const int32_t *ext_goal_t;        // [N]
+    const float *ext_adj;             // adjacency of the step (compact, or dense with ext_adj_ld = N)
+    int64_t ext_adj_ld;
+    const int64_t *ext_adj_off;       // block offsets matching ext_adj's layout
+    float *ce_acc;                    // [N]
 };
 
 #define W_TRY(x)                           \
@@ -299,39 +342,55 @@ extern "C" hipError_t dn_wide_goal_head(const WideStep *sp, hipStream_t st) {
     const int PF = s.P * s.F;
     const int64_t Gp = s.b.Gp;
     const float *hl = s.b.h + (int64_t)(s.L - 1) * rows * s.R;
+    if (s.P != 4 || s.F != 8) return hipErrorInvalidValue;
+    const bool teacher = s.ce_acc != nullptr;
+    const float *pos = teacher ? s.ext_pos : s.b.pos;
+    const int32_t *gprev = teacher ? s.ext_goal_prev : s.b.goal;
+    const float *adj = teacher ? s.ext_adj : s.b.adj;
+    const int64_t adj_ld = teacher ? s.ext_adj_ld : 0;
+    const int64_t *adj_off = teacher ? s.ext_adj_off : s.off_compact;
     // adjacency of every sample from the PRE-update positions (models/dagnet/model.py:215-220)
-    W_TRY(dn_launch_adjacency(s.adj_type, s.sigma, s.top_k, s.scene_ptr, s.row_scene, s.off_compact, s.N, s.K, s.b.pos, s.b.adj, 0,
-                              s.compact, st));
+    if (!teacher)
+        W_TRY(dn_launch_adjacency(s.adj_type, s.sigma, s.top_k, s.scene_ptr, s.row_scene, s.off_compact, s.N, s.K, s.b.pos, s.b.adj, 0,
+                                  s.compact, st));
     {
         const int64_t total = rows64 * s.b.a0_ld;
         hipLaunchKernelGGL(wide::goal_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s.N, s.K, s.D, s.R, s.b.a0_ld,
-                           s.scene_ptr, s.row_scene, s.b.pos, hl, s.b.A0);
+                           s.scene_ptr, s.row_scene, pos, hl, s.b.A0);
         W_TRY(hipGetLastError());
     }
     W_TRY(dn_gemm_nt_gather(s.b.A0, s.b.a0_ld, s.wp + s.w.g0_w, s.w.g0_ld, s.wp + s.w.g0_b, s.b.T1, s.H, rows, s.H, (int)s.b.a0_ld,
-                            wide::ACT_RELU, 0.f, s.wp + s.w.g0_gather, s.b.goal, s.w.g0_gld, st));
+                            wide::ACT_RELU, 0.f, s.wp + s.w.g0_gather, gprev, s.w.g0_gld, st));
     W_TRY(dn_gemm_nt_gather(s.b.T1, s.H, s.wp + s.w.g2_w, s.w.g2_ld, s.wp + s.w.g2_b, s.b.A1, 2 * Gp, rows, s.G, s.w.g2_ld,
                             wide::ACT_NONE, 0.f, nullptr, nullptr, 0, st));
     hipLaunchKernelGGL(wide::softmax_kernel, dim3((unsigned)((rows64 + 3) / 4)), dim3(256), 0, st, rows64, s.G, 2 * Gp, s.b.A1);
     W_TRY(hipGetLastError());
     W_TRY(dn_gemm_nt_gather(s.b.A1, 2 * Gp, s.wp + s.w.hf_w, s.w.hf_ld, nullptr, s.b.HS, s.b.hs_ld, rows, PF + 2 * s.P, (int)Gp,
                             wide::ACT_NONE, 0.f, nullptr, nullptr, 0, st));
-    if (s.P != 4 || s.F != 8) return hipErrorInvalidValue;
     {
         const int64_t total = rows64 * s.P;
         hipLaunchKernelGGL((wide::attn_heads_kernel<4, 8>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s.N, s.K,
-                           s.scene_ptr, s.row_scene, s.off_compact, s.compact, s.b.adj, s.b.HS, s.b.hs_ld, s.wp + s.w.fold_out,
+                           s.scene_ptr, s.row_scene, adj_off, s.compact, adj_ld, adj, s.b.HS, s.b.hs_ld, s.wp + s.w.fold_out,
                            s.alpha, s.b.X2, s.b.S2);
         W_TRY(hipGetLastError());
     }
     W_TRY(dn_gemm_nt_gather(s.b.X2, PF, s.wp + s.w.out_w, s.w.out_ld, nullptr, s.b.B, Gp, rows, s.G, PF, wide::ACT_NONE, 0.f,
                             nullptr, nullptr, 0, st));
-    hipLaunchKernelGGL(wide::attn_out_kernel, dim3((unsigned)(s.K * s.S)), dim3(256), 0, st, s.N, s.S, s.scene_ptr, s.off_compact,
-                       s.compact, s.b.adj, s.b.S2, s.alpha, s.b.B, Gp, s.G, s.wp + s.w.bn, s.b.A1 + Gp, 2 * Gp);
+    hipLaunchKernelGGL(wide::attn_out_kernel, dim3((unsigned)(s.K * s.S)), dim3(256), 0, st, s.N, s.S, s.scene_ptr, adj_off,
+                       s.compact, adj_ld, adj, s.b.S2, s.alpha, s.b.B, Gp, s.G, s.wp + s.w.bn, s.b.A1 + Gp, 2 * Gp);
     W_TRY(hipGetLastError());
     W_TRY(dn_gemm_nt_gather(s.b.A1, 2 * Gp, s.wp + s.w.lg_w, s.w.lg_ld, s.wp + s.w.lg_b, s.b.B, Gp, rows, s.G, (int)(2 * Gp),
                             wide::ACT_NONE, 0.f, nullptr, nullptr, 0, st));
-    hipLaunchKernelGGL(wide::draw_kernel, dim3((unsigned)((rows64 + 3) / 4)), dim3(256), 0, st, s.N, s.K, s.T, s.t, s.G, s.b.B, Gp, s.q,
-                       s.seed, s.force_goals, s.b.goal, s.out_goals);
+    if (teacher)
+        hipLaunchKernelGGL(wide::ce_kernel, dim3((unsigned)((rows64 + 3) / 4)), dim3(256), 0, st, rows64, s.G, s.b.B, Gp, s.ext_goal_t,
+                           s.ce_acc);
+    else
+        hipLaunchKernelGGL(wide::draw_kernel, dim3((unsigned)((rows64 + 3) / 4)), dim3(256), 0, st, s.N, s.K, s.T, s.t, s.G, s.b.B, Gp,
+                           s.q, s.seed, s.force_goals, s.b.goal, s.out_goals);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dn_wide_ce_finish(int64_t rows, const float *ce_acc, double *loss_part, hipStream_t st) {
+    hipLaunchKernelGGL(wide::ce_finish_kernel, dim3(1), dim3(1024), 0, st, rows, ce_acc, loss_part);
     return hipGetLastError();
 }

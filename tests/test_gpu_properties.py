@@ -328,3 +328,22 @@ def test_forward_kernels_agree(kind, kw, compact):
         for f, s, what in zip(fast[:3], slow[:3], ("KLD", "NLL", "CE")):
             assert abs(float(f) - float(s)) <= 1e-5 * max(1.0, abs(float(s))), what
         assert float((fast[3] - slow[3]).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("compact", [False, True])
+def test_wide_forward_agrees_with_generic_kernel(compact):
+    """Teacher-forced pass at g_dim = 960 on 40 ragged scenes: wide goal head + register-resident step kernel (model 3) against
+    the generic kernel with goal buffers in global scratch; dense and compact adjacency."""
+    from dagnet_amd.adjacency_matrix import compute_adjs_distsim
+    a, m, _ = _model("dagnet", n_max=32, seed=9, n_layers=2, g_dim=960)
+    sizes = [int(v) for v in syn.ragged_sizes(40, seed=6)]
+    obs, gt, obs_rel, gt_rel, og, pg, sse = [t.to(DEV) for t in syn.make_batch(sizes, 8, 4, 6, kind="sdd", g_cells=(32, 30))]
+    N = obs.shape[1]
+    adj = compute_adjs_distsim(a, sse, obs, gt, compact=compact)
+    eps = syn.uniform_noise(6, "eps", (7, N, 32)).to(DEV)
+    fast = m(obs, obs_rel, og.to(torch.int32), sse, adj, eps=eps)
+    with generic_kernel():
+        slow = m(obs, obs_rel, og.to(torch.int32), sse, adj, eps=eps)
+    for f, s, what in zip(fast[:3], slow[:3], ("KLD", "NLL", "CE")):
+        assert abs(float(f) - float(s)) <= 2e-5 * max(1.0, abs(float(s))), (what, float(f), float(s))
+    assert float((fast[3] - slow[3]).abs().max()) < 5e-5

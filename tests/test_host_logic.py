@@ -150,3 +150,27 @@ def test_random_state_dict_is_order_independent():
     shapes = {k: tuple(v.shape) for k, v in reversed(list(m.state_dict().items()))}
     sd2 = syn.random_state_dict(shapes, 9)
     assert all(torch.equal(sd[k], sd2[k]) for k in sd)
+
+
+def test_train_mode_forward_rejects_cpu_tensors():
+    """model.train() routes forward() to the HIP training operators; there is no CPU path behind them."""
+    a = syn.make_args()
+    m = dagnet_amd.VRNN(a).train()
+    with pytest.raises(_capi.DagnetHipError, match="no CPU path"):
+        m(torch.zeros(4, 3, 2))
+
+
+def test_gradient_arena_is_one_flat_buffer():
+    from dagnet_amd import _ops, training
+    a = syn.make_args(h_dim=16, z_dim=8, rnn_dim=16, n_layers=1)
+    m = dagnet_amd.AVRNN(a)
+    arena = training.attach_grad_arena(m)
+    params = list(m.parameters())
+    assert arena.numel() == sum(p.numel() for p in params) and float(arena.abs().sum()) == 0.0
+    off = 0
+    for p in params:
+        assert p.grad.shape == p.shape and p.grad.is_contiguous() and p.grad.data_ptr() == arena.data_ptr() + 4 * off
+        assert getattr(p, "_hip_sink") and isinstance(p._hip_defer, _ops.DeferredGrads)
+        off += p.numel()
+    arena.fill_(1.0)
+    assert all(float(p.grad.min()) == 1.0 for p in params)

@@ -1,7 +1,7 @@
 """Differentiable operators of the training step (row T), each a torch.autograd.Function whose forward and backward
 are HIP kernels behind the C ABI (dagnet_op_* in include/dagnet_hip.h: fp32 MFMA GEMMs of csrc/gemm_f32.hip, row-wise
 and per-scene kernels of csrc/train_ops.hip).  torch allocates the buffers and runs the autograd tape; no torch
-arithmetic happens in here.  There is no CPU path: every tensor must live on a ROCm device.
+arithmetic touches activations or gradients in here (only memsets and the reporting-only sqrt of the gradient norm).  There is no CPU path: every tensor must live on a ROCm device.
 
 All matrices are 2-D fp32 with unit column stride; a row-strided view (a column slice of a wider matrix) is passed as
 (pointer, row stride) without a copy.

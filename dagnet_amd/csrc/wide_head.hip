@@ -11,6 +11,8 @@
 //   A1[:, G:] = tanh(bn(attention over B))                wide_attn_out_kernel
 //   B  = A1 Wlg^T + blg                                   GEMM (K = 2G)
 //   goal = argmax_g exp(softmax(B)_g) / q_g               wide_draw_kernel
+// Teacher-forced pass (DAGNet.forward, models/dagnet/model.py:151-162): same layers with positions, previous goals and
+// adjacency taken from the batch, ending in ce_kernel (ce -= softmax(B)[g_t]) instead of the draw.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "params_wide.h"

@@ -25,9 +25,9 @@ extern "C" hipError_t dn_launch_adjacency(int type, double sigma, int top_k, con
 extern "C" hipError_t dn_launch_best_of_k(const int32_t *scene_ptr, int S, int N, int K, int T, const float *rel,
                                           const float *start, const float *gt, float *ade, float *fde, float *scene_best,
                                           double *sums, hipStream_t st);
-extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, const V2Weights *w, const V2Run *r, hipStream_t st);
-extern "C" int dn_v2_has(int model, int n_layers, int z_dim);
-extern "C" hipError_t dn_launch_forward_v2(int model, int n_layers, int z_dim, const V2Weights *w, const V2Run *r, hipStream_t st);
+extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *w, const V2Run *r, hipStream_t st);
+extern "C" int dn_v2_has(int model, int n_layers, int z_dim, int graph);
+extern "C" hipError_t dn_launch_forward_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *w, const V2Run *r, hipStream_t st);
 extern "C" hipError_t dn_launch_loss_finalize(int n_tiles, int N, const double *part, double *losses, hipStream_t st);
 extern "C" hipError_t dn_launch_abs_errors(int T, int N, const float *pred, const float *gt, float *ade, float *fde, hipStream_t st);
 extern "C" hipError_t dn_launch_scene_min_sum(const int32_t *scene_ptr, int S, int N, int K, const float *ade, const float *fde,
@@ -490,6 +490,39 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     return g;
 }
 
+// GCN in the V2Gat slots (v2_common.h gcn<>): heads = W1, fold = layer-1 scale|shift, out = W2, bn = layer-2 scale|shift;
+// bias and eval BatchNorm folded: y = agg * sc + ((b - mean) * sc + beta), sc = gamma / sqrt(var + eps)
+V2Gat v2_gcn(Packer &pk, const std::string &prefix, int nin, int nout, int F) {
+    V2Gat g;
+    memset(&g, 0, sizeof(g));
+    g.nout = nout;
+    const Tensor *W1 = pk.get(prefix + ".gc1.weight", {nin, F}), *W2 = pk.get(prefix + ".gc2.weight", {F, nout});
+    if (!W1 || !W2) return g;
+    const float *w1 = W1->p, *w2 = W2->p;
+    const float *b1 = nullptr, *b2 = nullptr;
+    if (pk.has(prefix + ".gc1.bias")) { const Tensor *b = pk.get(prefix + ".gc1.bias", {F}); if (b) b1 = b->p; }
+    if (pk.has(prefix + ".gc2.bias")) { const Tensor *b = pk.get(prefix + ".gc2.bias", {nout}); if (b) b2 = b->p; }
+    g.heads = pk.chain([=](int n, int k) { return w1[(size_t)k * F + n]; }, F, nin);
+    g.out = pk.chain([=](int n, int k) { return w2[(size_t)k * nout + n]; }, nout, F);
+    auto fold = [&](const std::string &bn, int n, const float *bias, int ld) {
+        const Tensor *ga = pk.get(bn + ".weight", {n}), *be = pk.get(bn + ".bias", {n});
+        const Tensor *mu = pk.get(bn + ".running_mean", {n}), *var = pk.get(bn + ".running_var", {n});
+        if (!ga || !be || !mu || !var) return -1;
+        const float *gp = ga->p, *bp = be->p, *mp = mu->p, *vp = var->p;
+        return pk.vec(
+            [=](int i) {
+                const int c = i % ld, row = i / ld;
+                if (c >= n) return 0.0f;
+                const float sc = gp[c] / sqrtf(vp[c] + 1e-5f);
+                return row == 0 ? sc : ((bias ? bias[c] : 0.f) - mp[c]) * sc + bp[c];
+            },
+            2 * ld, 2 * ld);
+    };
+    g.fold = fold(prefix + ".bn1", F, b1, 32);
+    g.bn = fold(prefix + ".bn2", nout, b2, pad32(nout));
+    return g;
+}
+
 V2Gru v2_gru(Packer &pk, int l, int R, int H) {
     V2Gru g;
     memset(&g, 0, sizeof(g));
@@ -519,9 +552,10 @@ V2Gru v2_gru(Packer &pk, int l, int R, int H) {
 bool v2_eligible(const dagnet_config &c) {
     if (c.model < 0 || c.model > 2) return false;
     if (c.x_dim != 2 || c.h_dim != 64 || c.rnn_dim != 64) return false;
-    if (!dn_v2_has(c.model, c.n_layers, c.z_dim)) return false;
+    if (!dn_v2_has(c.model, c.n_layers, c.z_dim, c.model == DAGNET_MODEL_VRNN ? 0 : c.graph_model)) return false;
     if (c.model != DAGNET_MODEL_VRNN) {
-        if (c.graph_model != DAGNET_GRAPH_GAT || c.n_heads != 4 || c.graph_hid != 8) return false;
+        if (c.graph_model == DAGNET_GRAPH_GAT && (c.n_heads != 4 || c.graph_hid != 8)) return false;
+        if (c.graph_model == DAGNET_GRAPH_GCN && c.graph_hid > 32) return false;
         if (c.adjacency_type != 0 && c.adjacency_type != 1) return false;
     }
     if (c.model == DAGNET_MODEL_DAGNET && (c.g_dim > 96 || c.n_max_agents > 16)) return false;
@@ -534,7 +568,7 @@ static inline int pad4(int x) { return (x + 3) & ~3; }
 bool wide_eligible(const dagnet_config &c) {
     if (c.model != DAGNET_MODEL_DAGNET) return false;
     if (c.x_dim != 2 || c.h_dim != 64 || c.rnn_dim != 64) return false;
-    if (!dn_v2_has(3, c.n_layers, c.z_dim)) return false;
+    if (!dn_v2_has(3, c.n_layers, c.z_dim, DAGNET_GRAPH_GAT)) return false;
     if (c.graph_model != DAGNET_GRAPH_GAT || c.n_heads != 4 || c.graph_hid != 8) return false;
     if (c.adjacency_type != 0 && c.adjacency_type != 1) return false;
     if (c.g_dim <= 96 || (c.g_dim & 3) || c.n_max_agents > 32) return false;
@@ -638,13 +672,15 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
     W.dec2 = v2_linear(pk, "dec.2", H, H, {{0, H}});
     for (int l = 0; l < c.n_layers; ++l) W.gru[l] = v2_gru(pk, l, R, H);
     if (graph) {
-        W.g_hid = v2_gat(pk, dag ? "graph_hiddens" : "graph", R, R, c.graph_hid, c.n_heads);
+        W.g_hid = c.graph_model == DAGNET_GRAPH_GCN ? v2_gcn(pk, dag ? "graph_hiddens" : "graph", R, R, c.graph_hid)
+                                                    : v2_gat(pk, dag ? "graph_hiddens" : "graph", R, R, c.graph_hid, c.n_heads);
         W.blend = v2_linear(pk, dag ? "lg_hiddens" : "lg", R, 2 * R, {{0, R}, {R, R}});
     }
     if (dag && !ext) {
         W.dec_goal0 = v2_linear(pk, "dec_goal.0", H, Dd + R + G, {{0, Dd}, {Dd, R}}, Dd + R, G);
         W.dec_goal2 = v2_linear(pk, "dec_goal.2", G, H, {{0, H}});
-        W.g_goal = v2_gat(pk, "graph_goals", G, G, c.graph_hid, c.n_heads);
+        W.g_goal = c.graph_model == DAGNET_GRAPH_GCN ? v2_gcn(pk, "graph_goals", G, G, c.graph_hid)
+                                                     : v2_gat(pk, "graph_goals", G, G, c.graph_hid, c.n_heads);
         W.lg_goals = v2_linear(pk, "lg_goals.0", G, 2 * G, {{0, G}, {G, G}});
     }
 }
@@ -1090,7 +1126,7 @@ extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_
         if (getenv("DAGNET_V2_DUMP")) r.dbg = reinterpret_cast<float *>(g_prof);
         else r.prof = g_prof;
 #endif
-        HIP_TRY(dn_launch_rollout_v2(m->dims.model, m->dims.L, m->dims.Z, m->d_w2, &r, static_cast<hipStream_t>(stream)));
+        HIP_TRY(dn_launch_rollout_v2(m->dims.model, m->dims.L, m->dims.Z, m->dims.graph, m->d_w2, &r, static_cast<hipStream_t>(stream)));
         return DAGNET_OK;
     }
     if (m->wide && p->wide && !getenv("DAGNET_FORCE_GENERIC")) {
@@ -1119,7 +1155,7 @@ extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_
             ws.t = t;
             HIP_TRY(dn_wide_goal_head(&ws, st));
             r.t_begin = t; r.t_end = t + 1;
-            HIP_TRY(dn_launch_rollout_v2(3, D.L, D.Z, m->d_w2, &r, st));
+            HIP_TRY(dn_launch_rollout_v2(3, D.L, D.Z, D.graph, m->d_w2, &r, st));
         }
         return DAGNET_OK;
     }
@@ -1197,7 +1233,7 @@ extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32
             ws.ext_adj = P.r.adj + (int64_t)t * P.r.adj_tstride;
             HIP_TRY(dn_wide_goal_head(&ws, st));
             r.t_begin = t; r.t_end = t + 1;
-            HIP_TRY(dn_launch_forward_v2(3, D.L, D.Z, m->d_w2, &r, st));
+            HIP_TRY(dn_launch_forward_v2(3, D.L, D.Z, D.graph, m->d_w2, &r, st));
         }
         HIP_TRY(dn_wide_ce_finish(N, ce_acc, p->d_loss_part, st));
         HIP_TRY(dn_launch_loss_finalize(p->n_tiles2, p->N, p->d_loss_part, d_losses, st));
@@ -1215,7 +1251,7 @@ extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32
         r.traj = d_traj; r.traj_rel = d_traj_rel; r.goals = d_goals;
         r.adj = P.r.adj; r.adj_ld = P.r.adj_ld; r.adj_tstride = P.r.adj_tstride; r.adj_off = P.r.adj_off;
         r.loss_part = p->d_loss_part;
-        HIP_TRY(dn_launch_forward_v2(m->dims.model, m->dims.L, m->dims.Z, m->d_w2, &r, st));
+        HIP_TRY(dn_launch_forward_v2(m->dims.model, m->dims.L, m->dims.Z, m->dims.graph, m->d_w2, &r, st));
         HIP_TRY(dn_launch_loss_finalize(p->n_tiles2, p->N, p->d_loss_part, d_losses, st));
         return DAGNET_OK;
     }

@@ -15,7 +15,7 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-template <int MODEL, int NL, int ZD>
+template <int MODEL, int NL, int ZD, int GM>
 __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
     const V2Weights &W = *Wp;
     __shared__ float xch[32 * 4 + 64];
@@ -91,6 +91,13 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
             }
             amask = mk;
         }
+        // GCN: the adjacency VALUES of the step (same addressing as the mask above)
+        auto adjval = [&](int r) -> float {
+            const int j = FR(r) + 4 * lh;
+            const bool in = (j >= s0) & (j < s0 + n) & live;
+            const float v = (R.adj + (int64_t)t * R.adj_tstride + arow_off)[in ? j - s0 : 0];
+            return in ? v : (j == lc ? 1.0f : 0.f);
+        };
         int gt = 0;
         T16 d[DT];
         auto build_disposition = [&]() {
@@ -138,7 +145,8 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
             zero(gc);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.g_goal.heads);
             T16 gg[GT];
-            pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1]);
+            if constexpr (GM == 2) pre = gcn<GT, GT>(decg, gg, wp, W.g_goal, adjval, lane, pre, W.lg_goals.w[1]);
+            else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1]);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.phi_x2.w[0]);
             finish<0, GT>(gc, wp, W.lg_goals, 0, lh);
             softmax_feat<GT>(gc, R.G, lh);
@@ -313,7 +321,8 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
         // -------------------------------------------------------------------- graph refinement of h[-1]
         if constexpr (GRAPH) {
             T16 hg[2];
-            pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, lane, pre, W.blend.w[0]);
+            if constexpr (GM == 2) pre = gcn<2, 2>(h[NL - 1], hg, wp, W.g_hid, adjval, lane, pre, W.blend.w[0]);
+            else pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, lane, pre, W.blend.w[0]);
             zero(ta);
             pre = mm<2, 2, false>(ta, wp, W.blend.w[0], hg, lane, pre, W.blend.w[1]);
             pre = mm<2, 2, false>(ta, wp, W.blend.w[1], h[NL - 1], lane, pre, first_off);
@@ -345,17 +354,21 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
 
 }   // namespace v2
 
-template <int MODEL, int NL, int ZD>
+template <int MODEL, int NL, int ZD, int GM>
 static hipError_t launch_fwd(const V2Weights *d_w, const V2Run &r, hipStream_t st) {
-    hipLaunchKernelGGL((v2::forward_v2_kernel<MODEL, NL, ZD>), dim3(r.n_tiles), dim3(64), 0, st, d_w, r);
+    hipLaunchKernelGGL((v2::forward_v2_kernel<MODEL, NL, ZD, GM>), dim3(r.n_tiles), dim3(64), 0, st, d_w, r);
     return hipGetLastError();
 }
 
-#define V2F_INSTANCES V2_CASE(2, 2, 32) V2_CASE(1, 1, 32) V2_CASE(0, 2, 32) V2_CASE(1, 1, 16) V2_CASE(0, 2, 16) V2_CASE(1, 2, 32) V2_CASE(3, 2, 32)
+#define V2F_INSTANCES                                                                                                  \
+    V2_CASE(2, 2, 32, 1) V2_CASE(1, 1, 32, 1) V2_CASE(0, 2, 32, 1) V2_CASE(1, 1, 16, 1) V2_CASE(0, 2, 16, 1) V2_CASE(1, 2, 32, 1) \
+    V2_CASE(3, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2)
 
-extern "C" hipError_t dn_launch_forward_v2(int model, int n_layers, int z_dim, const V2Weights *d_w, const V2Run *r, hipStream_t st) {
-#define V2_CASE(M, L, Z) \
-    if (model == M && n_layers == L && z_dim == Z) return launch_fwd<M, L, Z>(d_w, *r, st);
+extern "C" hipError_t dn_launch_forward_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *d_w, const V2Run *r,
+                                           hipStream_t st) {
+    const int gm = graph == 2 ? 2 : 1;
+#define V2_CASE(M, L, Z, G) \
+    if (model == M && n_layers == L && z_dim == Z && gm == G) return launch_fwd<M, L, Z, G>(d_w, *r, st);
     V2F_INSTANCES
 #undef V2_CASE
     return hipErrorInvalidValue;

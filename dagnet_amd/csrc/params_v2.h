@@ -14,6 +14,8 @@ struct V2Lin {
     int32_t gather;    // one-hot table [G][NT*32], -1 = none
 };
 
+// GCN models reuse the slots (api.hip v2_gcn, v2_common.h gcn<>): heads = W1, fold = [2][32] layer-1 scale | shift,
+// out = W2, bn = [2][NT*32] layer-2 scale | shift.
 struct V2Gat {
     int32_t heads;     // chain-packed [1 tile out (P*F = 32)][KT]       (S->T product)
     int32_t fold;      // chain-packed [1 tile out][KT]: features 0..P-1 = W.a_src, P..2P-1 = W.a_dst

@@ -26,7 +26,8 @@ namespace v2 {
 // MODEL: 0 VRNN, 1 A-VRNN, 2 DAG-Net, 3 DAG-Net whose goal head runs outside this kernel (wide_head.hip: the goal of the
 // step is read from the per-sample goal state; state is per (sample, row) and written back after the last step).
 // NL: GRU layers.  ZT: 32 -> z_dim 32, 16 -> z_dim 16.
-template <int MODEL, int NL, int ZD>
+// GM: 1 = GAT (4 heads x 8), 2 = GCN (graph_hid <= 32).
+template <int MODEL, int NL, int ZD, int GM>
 __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
     const V2Weights &W = *Wp;     // offsets are fetched with scalar loads where they are used (no SGPR residency)
     __shared__ float xch[32 * 4 + 64];
@@ -140,6 +141,19 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             }
             amask = mk;
         };
+        // GCN: this lane's row of the adjacency, from the positions build_mask() left in LDS
+        // (adjacency_matrix.py:21-28,49-58: 1 inside the scene, or exp(-d / sigma) with d in fp64; exp itself in fp32 here)
+        auto adjval = [&](int r) -> float {
+            const int j = FR(r) + 4 * lh;
+            const bool in = (j >= s0) & (j < s0 + n);
+            float v = 1.0f;
+            if (R.adj_type == 1) {
+                const float2 pj = *reinterpret_cast<const float2 *>(pos + j * 2);
+                const double dx = (double)xa - (double)pj.x, dy = (double)ya - (double)pj.y;
+                v = fexp(-(float)sqrt(dx * dx + dy * dy) * (float)(1.0 / R.sigma));
+            }
+            return in ? v : 0.f;
+        };
         T16 d[DT];
         auto build_disposition = [&]() {    // flattened xy of the scene's agents, zero padded
 #pragma unroll
@@ -185,7 +199,8 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             zero(gc);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.g_goal.heads);
             T16 gg[GT];
-            pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1]);
+            if constexpr (GM == 2) pre = gcn<GT, GT>(decg, gg, wp, W.g_goal, adjval, lane, pre, W.lg_goals.w[1]);
+            else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1]);
             PH(2);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.prior0.w[0]);
             finish<0, GT>(gc, wp, W.lg_goals, 0, lh);
@@ -389,7 +404,8 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         }
         if (GRAPH) {
             T16 hg[2];
-            pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, lane, pre, W.blend.w[0]);
+            if constexpr (GM == 2) pre = gcn<2, 2>(h[NL - 1], hg, wp, W.g_hid, adjval, lane, pre, W.blend.w[0]);
+            else pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, lane, pre, W.blend.w[0]);
             zero(ta);
             pre = mm<2, 2, false>(ta, wp, W.blend.w[0], hg, lane, pre, W.blend.w[1]);
             pre = mm<2, 2, false>(ta, wp, W.blend.w[1], h[NL - 1], lane, pre, first_off);
@@ -420,30 +436,34 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 
 }   // namespace v2
 
-template <int MODEL, int NL, int ZD>
+template <int MODEL, int NL, int ZD, int GM>
 static hipError_t launch_one(const V2Weights *d_w, const V2Run &r, hipStream_t st) {
-    hipLaunchKernelGGL((v2::rollout_v2_kernel<MODEL, NL, ZD>), dim3(r.n_tiles), dim3(64), 0, st, d_w, r);
+    hipLaunchKernelGGL((v2::rollout_v2_kernel<MODEL, NL, ZD, GM>), dim3(r.n_tiles), dim3(64), 0, st, d_w, r);
     return hipGetLastError();
 }
 
-// (model, GRU layers, z_dim) combinations with an instantiation: the shapes of the shipped checkpoints
-// (basketball: DAG-Net L2/Z32, A-VRNN L1/Z32, VRNN L2/Z32; SDD: A-VRNN L1/Z16, VRNN L2/Z16) plus A-VRNN L2/Z32
-#define V2_INSTANCES \
-    V2_CASE(2, 2, 32) V2_CASE(1, 1, 32) V2_CASE(0, 2, 32) V2_CASE(1, 1, 16) V2_CASE(0, 2, 16) V2_CASE(1, 2, 32) V2_CASE(3, 2, 32)
+// (model, GRU layers, z_dim, graph) combinations with an instantiation: the shapes of the shipped checkpoints
+// (basketball: DAG-Net L2/Z32, A-VRNN L1/Z32, VRNN L2/Z32; SDD: A-VRNN L1/Z16, VRNN L2/Z16) plus A-VRNN L2/Z32, model 3
+// (goal head outside) and the GCN variants of the graph models.  graph: 0 none (VRNN), 1 GAT, 2 GCN.
+#define V2_INSTANCES                                                                                                   \
+    V2_CASE(2, 2, 32, 1) V2_CASE(1, 1, 32, 1) V2_CASE(0, 2, 32, 1) V2_CASE(1, 1, 16, 1) V2_CASE(0, 2, 16, 1) V2_CASE(1, 2, 32, 1) \
+    V2_CASE(3, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2)
 
-// returns hipErrorInvalidValue when the (model, layers, z) combination has no instantiation
-// d_w: DEVICE pointer to the model's V2Weights table
-extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, const V2Weights *d_w, const V2Run *r, hipStream_t st) {
-#define V2_CASE(M, L, Z) \
-    if (model == M && n_layers == L && z_dim == Z) return launch_one<M, L, Z>(d_w, *r, st);
+// returns hipErrorInvalidValue when the combination has no instantiation; d_w: DEVICE pointer to the model's V2Weights table
+extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *d_w, const V2Run *r,
+                                           hipStream_t st) {
+    const int gm = graph == 2 ? 2 : 1;
+#define V2_CASE(M, L, Z, G) \
+    if (model == M && n_layers == L && z_dim == Z && gm == G) return launch_one<M, L, Z, G>(d_w, *r, st);
     V2_INSTANCES
 #undef V2_CASE
     return hipErrorInvalidValue;
 }
 
-extern "C" int dn_v2_has(int model, int n_layers, int z_dim) {
-#define V2_CASE(M, L, Z) \
-    if (model == M && n_layers == L && z_dim == Z) return 1;
+extern "C" int dn_v2_has(int model, int n_layers, int z_dim, int graph) {
+    const int gm = graph == 2 ? 2 : 1;
+#define V2_CASE(M, L, Z, G) \
+    if (model == M && n_layers == L && z_dim == Z && gm == G) return 1;
     V2_INSTANCES
 #undef V2_CASE
     return 0;

@@ -284,6 +284,53 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     return pre;
 }
 
+// Dense GCN (gcn_model.py:14-19: gc1 -> BatchNorm -> gc2 -> BatchNorm -> tanh, gc(x) = adj @ (x W) + b, gcn_layers.py:20-26)
+// on the tile, with the same transposed-product trick as gat<>: (x W)^T is the A operand and this lane's row of the
+// adjacency (adjv(r) = adj[row][tile row FR(r) + 4*lh], 0 outside the scene) the B operand of the aggregation.
+// V2Gat fields as used here: heads = W1 [1 tile (F <= 32)][KT], fold = [2][32] scale | shift of layer 1 (bias and eval
+// BatchNorm folded, zero beyond F), out = W2 [NT][1], bn = [2][NT*32] scale | shift of layer 2.
+template <int KT, int NT, class AdjFn>
+__device__ __forceinline__ WBlk gcn(const T16 (&x)[KT], T16 (&out)[NT], const WBuf &wp, const V2Gat &Gw, AdjFn adjv, int lane,
+                                    WBlk pre, int next_off) {
+    const int lh = lane >> 5;
+    T16 whT[1];
+    zero(whT);
+    pre = mm<1, KT, true>(whT, wp, Gw.heads, x, lane, pre, Gw.out);
+    float av[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) av[r] = adjv(r);
+    T16 x1[1];
+    zero(x1);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x1[0] = MFMA(whT[0][r], av[r], x1[0]);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float4 sc = wp.ld4(lh * 16, Gw.fold + 8 * a), sh = wp.ld4(lh * 16, Gw.fold + 32 + 8 * a);
+        x1[0][4 * a + 0] = x1[0][4 * a + 0] * sc.x + sh.x; x1[0][4 * a + 1] = x1[0][4 * a + 1] * sc.y + sh.y;
+        x1[0][4 * a + 2] = x1[0][4 * a + 2] * sc.z + sh.z; x1[0][4 * a + 3] = x1[0][4 * a + 3] * sc.w + sh.w;
+    }
+    zero(out);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        T16 wh2T[1];
+        zero(wh2T);
+        pre = mm<1, 1, true>(wh2T, wp, Gw.out + nt * 1024, x1, lane, pre, nt + 1 < NT ? Gw.out + (nt + 1) * 1024 : next_off);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], av[r], out[nt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int fs = nt * 32 + 8 * a;
+            const float4 sc = wp.ld4(lh * 16, Gw.bn + fs), sh = wp.ld4(lh * 16, Gw.bn + NT * 32 + fs);
+            const float g4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[nt][4 * a + i] = ftanh(out[nt][4 * a + i] * g4[i] + b4[i]);
+        }
+    return pre;
+}
+
 // One GRU layer.  xin: KX input tiles; h: 2 tiles (R = 64), updated in place.
 template <int KX>
 __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBuf &wp, const V2Gru &Gw, int lane, WBlk pre,

@@ -45,7 +45,8 @@ class generic_kernel:
         del os.environ["DAGNET_FORCE_GENERIC"]
 
 
-@pytest.mark.parametrize("kind,kw", [("vrnn", dict(n_layers=2)), ("avrnn", dict(n_layers=1)), ("dagnet", dict(n_layers=2))])
+@pytest.mark.parametrize("kind,kw", [("vrnn", dict(n_layers=2)), ("avrnn", dict(n_layers=1)), ("dagnet", dict(n_layers=2)),
+                                     ("avrnn", dict(n_layers=1, graph_model="gcn")), ("dagnet", dict(n_layers=2, graph_model="gcn"))])
 def test_both_kernels_agree_and_are_deterministic(kind, kw):
     """Same seed -> the register-resident and the generic kernel draw the same Philox numbers; trajectories agree to
     fp32 reordering noise, goal indices exactly; a second launch is bitwise identical; another seed differs."""
@@ -261,7 +262,7 @@ def test_errors_are_loud():
     ("avrnn_sdd_gat", "register-resident"), ("vrnn_sdd", "register-resident"), ("avrnn_bsk_gat_L2_n10", "register-resident"),
     ("dagnet_bsk_gat_ragged_1_32", "LDS-tiled"),      # n_max_agents = 32 > 16: disposition wider than one k-tile
     ("avrnn_bsk_gat_n33", "LDS-tiled"),               # a 33-agent scene does not fit a 32-row wave tile
-    ("dagnet_bsk_gcn_n10", "LDS-tiled"), ("dagnet_tiny_gat_adj1", "LDS-tiled"), ("dagnet_sdd_gat_g960", "wide goal head"), ("dagnet_sdd_gcn_g960", "global scratch"),
+    ("dagnet_bsk_gcn_n10", "register-resident"), ("dagnet_tiny_gat_adj1", "LDS-tiled"), ("dagnet_sdd_gat_g960", "wide goal head"), ("dagnet_sdd_gcn_g960", "global scratch"),
 ])
 def test_kernel_dispatch(name, want):
     """Which kernel a golden case runs on (the parity tests cover both kernels only if the dispatch is as intended)."""
@@ -300,7 +301,8 @@ def test_wide_goal_head_agrees_with_generic_kernel_on_ragged_sdd_batch():
     assert torch.equal(s2, s_w), "the wide path is not deterministic for a fixed seed"
 
 
-@pytest.mark.parametrize("kind,kw", [("vrnn", dict(n_layers=2)), ("avrnn", dict(n_layers=1)), ("dagnet", dict(n_layers=2))])
+@pytest.mark.parametrize("kind,kw", [("vrnn", dict(n_layers=2)), ("avrnn", dict(n_layers=1)), ("dagnet", dict(n_layers=2)),
+                                     ("avrnn", dict(n_layers=2, graph_model="gcn")), ("dagnet", dict(n_layers=2, graph_model="gcn"))])
 @pytest.mark.parametrize("compact", [False, True])
 def test_forward_kernels_agree(kind, kw, compact):
     """Teacher-forced pass: the register-resident kernel (forward_v2.hip) against the generic one on 41 ragged scenes, dense and

@@ -558,7 +558,8 @@ bool v2_eligible(const dagnet_config &c) {
         if (c.graph_model == DAGNET_GRAPH_GCN && c.graph_hid > 32) return false;
         if (c.adjacency_type != 0 && c.adjacency_type != 1) return false;
     }
-    if (c.model == DAGNET_MODEL_DAGNET && (c.g_dim > 96 || c.n_max_agents > 16)) return false;
+    if (c.model == DAGNET_MODEL_DAGNET && (c.g_dim > 96 || c.n_max_agents > 32)) return false;
+    if (c.model == DAGNET_MODEL_DAGNET && c.n_max_agents > 16 && !dn_v2_has(4, c.n_layers, c.z_dim, c.graph_model)) return false;
     return true;
 }
 
@@ -654,7 +655,7 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
     if (dag) {
         W.prior0 = v2_linear(pk, "prior.0", H, G + R, {{G, R}}, 0, G);
         // model 3 multiplies two disposition tiles whatever n_max_agents is
-        W.dec0 = v2_linear(pk, "dec.0", H, Dd + G + H + R, {{0, Dd, ext ? 64 : 0}, {Dd + G, H}, {Dd + G + H, R}}, Dd, G);
+        W.dec0 = v2_linear(pk, "dec.0", H, Dd + G + H + R, {{0, Dd, (ext || Dd > 32) ? 64 : 0}, {Dd + G, H}, {Dd + G + H, R}}, Dd, G);
     } else {
         W.prior0 = v2_linear(pk, "prior.0", H, R, {{0, R}});
         W.dec0 = v2_linear(pk, "dec.0", H, H + R, {{0, H}, {H, R}});
@@ -677,7 +678,7 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
         W.blend = v2_linear(pk, dag ? "lg_hiddens" : "lg", R, 2 * R, {{0, R}, {R, R}});
     }
     if (dag && !ext) {
-        W.dec_goal0 = v2_linear(pk, "dec_goal.0", H, Dd + R + G, {{0, Dd}, {Dd, R}}, Dd + R, G);
+        W.dec_goal0 = v2_linear(pk, "dec_goal.0", H, Dd + R + G, {{0, Dd, Dd > 32 ? 64 : 0}, {Dd, R}}, Dd + R, G);
         W.dec_goal2 = v2_linear(pk, "dec_goal.2", G, H, {{0, H}});
         W.g_goal = c.graph_model == DAGNET_GRAPH_GCN ? v2_gcn(pk, "graph_goals", G, G, c.graph_hid)
                                                      : v2_gat(pk, "graph_goals", G, G, c.graph_hid, c.n_heads);
@@ -1061,6 +1062,9 @@ extern "C" int dagnet_plan_info(const dagnet_plan *p, int32_t *tile_rows, int32_
     return DAGNET_OK;
 }
 
+// template instance of the register-resident kernels: DAG-Net with more than 16 agents per scene needs two disposition tiles
+static int v2_model_code(const dagnet_model *m) { return m->dims.model == DAGNET_MODEL_DAGNET && m->dims.D > 32 ? 4 : m->dims.model; }
+
 static int check_plan(const dagnet_model *m, const dagnet_plan *p) {
     if (!p->d_static || p->n_tiles < 1) return fail(DAGNET_ERR_INVALID, "plan was created without a model (tables only)");
     if (p->owner != m) return fail(DAGNET_ERR_INVALID, "plan was created for another model");
@@ -1126,7 +1130,7 @@ extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_
         if (getenv("DAGNET_V2_DUMP")) r.dbg = reinterpret_cast<float *>(g_prof);
         else r.prof = g_prof;
 #endif
-        HIP_TRY(dn_launch_rollout_v2(m->dims.model, m->dims.L, m->dims.Z, m->dims.graph, m->d_w2, &r, static_cast<hipStream_t>(stream)));
+        HIP_TRY(dn_launch_rollout_v2(v2_model_code(m), m->dims.L, m->dims.Z, m->dims.graph, m->d_w2, &r, static_cast<hipStream_t>(stream)));
         return DAGNET_OK;
     }
     if (m->wide && p->wide && !getenv("DAGNET_FORCE_GENERIC")) {
@@ -1251,7 +1255,7 @@ extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32
         r.traj = d_traj; r.traj_rel = d_traj_rel; r.goals = d_goals;
         r.adj = P.r.adj; r.adj_ld = P.r.adj_ld; r.adj_tstride = P.r.adj_tstride; r.adj_off = P.r.adj_off;
         r.loss_part = p->d_loss_part;
-        HIP_TRY(dn_launch_forward_v2(m->dims.model, m->dims.L, m->dims.Z, m->dims.graph, m->d_w2, &r, st));
+        HIP_TRY(dn_launch_forward_v2(v2_model_code(m), m->dims.L, m->dims.Z, m->dims.graph, m->d_w2, &r, st));
         HIP_TRY(dn_launch_loss_finalize(p->n_tiles2, p->N, p->d_loss_part, d_losses, st));
         return DAGNET_OK;
     }

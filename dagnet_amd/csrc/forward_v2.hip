@@ -19,16 +19,16 @@ template <int MODEL, int NL, int ZD, int GM>
 __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
     const V2Weights &W = *Wp;
     __shared__ float xch[32 * 4 + 64];
-    __shared__ float stash[MODEL == 2 ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
+    __shared__ float stash[(MODEL == 2 || MODEL == 4) ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
     float *pos = xch + 128;
     const int lane = threadIdx.x, lc = lane & 31;
     WBuf wp;
     wp.init(R.wp);
     // MODEL 3: DAG-Net whose goal head (and its CE term) runs outside (wide_head.hip); steps [t_begin, t_end) per launch,
     // hidden state read from / written back to h_out, loss partials accumulated over the launches
-    constexpr bool DAG = MODEL >= 2, HEAD = MODEL == 2, EXT = MODEL == 3, GRAPH = MODEL != 0;
+    constexpr bool DAG = MODEL >= 2, HEAD = MODEL == 2 || MODEL == 4, EXT = MODEL == 3, GRAPH = MODEL != 0;
     constexpr int GT = 3;
-    constexpr int DT = EXT ? 2 : 1;
+    constexpr int DT = (EXT || MODEL == 4) ? 2 : 1;
     constexpr int MLT = ZD == 32 ? 2 : 1;
 
     // ---- rows of this wave (K = 1: unit = scene)
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
             // ---------------------------------------------------------------- goal head (teacher forced: g_{t-1} in, CE on g_t)
             T16 tg[2];
             zero(tg);
-            pre = mm<2, 1, false>(tg, wp, W.dec_goal0.w[0], d, lane, pre, W.dec_goal0.w[1]);
+            pre = mm<2, DT, false>(tg, wp, W.dec_goal0.w[0], d, lane, pre, W.dec_goal0.w[1]);
             pre = mm<2, 2, false>(tg, wp, W.dec_goal0.w[1], h[NL - 1], lane, pre, W.dec_goal2.w[0]);
             finish<2, 2>(tg, wp, W.dec_goal0, gprev, lh);
 #pragma unroll
@@ -362,7 +362,7 @@ static hipError_t launch_fwd(const V2Weights *d_w, const V2Run &r, hipStream_t s
 
 #define V2F_INSTANCES                                                                                                  \
     V2_CASE(2, 2, 32, 1) V2_CASE(1, 1, 32, 1) V2_CASE(0, 2, 32, 1) V2_CASE(1, 1, 16, 1) V2_CASE(0, 2, 16, 1) V2_CASE(1, 2, 32, 1) \
-    V2_CASE(3, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2)
+    V2_CASE(3, 2, 32, 1) V2_CASE(4, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2)
 
 extern "C" hipError_t dn_launch_forward_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *d_w, const V2Run *r,
                                            hipStream_t st) {

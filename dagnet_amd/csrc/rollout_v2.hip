@@ -23,7 +23,7 @@
 
 namespace v2 {
 
-// MODEL: 0 VRNN, 1 A-VRNN, 2 DAG-Net, 3 DAG-Net whose goal head runs outside this kernel (wide_head.hip: the goal of the
+// MODEL: 0 VRNN, 1 A-VRNN, 2 DAG-Net, 4 DAG-Net with 17..32 agents per scene (two disposition tiles), 3 DAG-Net whose goal head runs outside this kernel (wide_head.hip: the goal of the
 // step is read from the per-sample goal state; state is per (sample, row) and written back after the last step).
 // NL: GRU layers.  ZT: 32 -> z_dim 32, 16 -> z_dim 16.
 // GM: 1 = GAT (4 heads x 8), 2 = GCN (graph_hid <= 32).
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     // DAG-Net: hidden state parked in LDS while the goal head needs the registers ([tile][reg][lane], conflict free)
     // also (NL == 2): the top layer's state is parked while GRU layer 0 runs (its 4 input tiles + 2 state tiles + gate
     // temporaries do not fit beside it; the compiler would spill ~140 registers to scratch memory instead)
-    __shared__ float stash[MODEL == 2 ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
+    __shared__ float stash[(MODEL == 2 || MODEL == 4) ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
     float *pos = xch + 128;                 // [32][2] current absolute positions of the tile rows
     const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
 #ifdef DN_V2_STAGGER
@@ -46,9 +46,9 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #endif
     WBuf wp;
     wp.init(R.wp);
-    constexpr bool DAG = MODEL >= 2, GRAPH = MODEL != 0, HEAD = MODEL == 2, EXT = MODEL == 3;
+    constexpr bool DAG = MODEL >= 2, GRAPH = MODEL != 0, HEAD = MODEL == 2 || MODEL == 4, EXT = MODEL == 3;
     constexpr int GT = 3;                   // goal tiles (g_dim <= 96)
-    constexpr int DT = EXT ? 2 : 1;         // disposition tiles (2 * n_max_agents <= 32 * DT)
+    constexpr int DT = (EXT || MODEL == 4) ? 2 : 1;         // disposition tiles (2 * n_max_agents <= 32 * DT)
     const int t_begin = EXT ? R.t_begin : 0, t_end = EXT ? R.t_end : R.T;
 
     // ---- which rows does this wave own?  (uniform scalar walk over the tile's scene-samples)
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             // ---------------------------------------------------------------- goal head
             T16 tg[2];
             zero(tg);
-            pre = mm<2, 1, false>(tg, wp, W.dec_goal0.w[0], d, lane, pre, W.dec_goal0.w[1]);
+            pre = mm<2, DT, false>(tg, wp, W.dec_goal0.w[0], d, lane, pre, W.dec_goal0.w[1]);
             pre = mm<2, 2, false>(tg, wp, W.dec_goal0.w[1], h[NL - 1], lane, pre, W.dec_goal2.w[0]);
             finish<2, 2>(tg, wp, W.dec_goal0, gi, lh);
             // the top-layer hidden state is not read again until the prior: park it as well
@@ -447,7 +447,7 @@ static hipError_t launch_one(const V2Weights *d_w, const V2Run &r, hipStream_t s
 // (goal head outside) and the GCN variants of the graph models.  graph: 0 none (VRNN), 1 GAT, 2 GCN.
 #define V2_INSTANCES                                                                                                   \
     V2_CASE(2, 2, 32, 1) V2_CASE(1, 1, 32, 1) V2_CASE(0, 2, 32, 1) V2_CASE(1, 1, 16, 1) V2_CASE(0, 2, 16, 1) V2_CASE(1, 2, 32, 1) \
-    V2_CASE(3, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2)
+    V2_CASE(3, 2, 32, 1) V2_CASE(4, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2)
 
 // returns hipErrorInvalidValue when the combination has no instantiation; d_w: DEVICE pointer to the model's V2Weights table
 extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *d_w, const V2Run *r,

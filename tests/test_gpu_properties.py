@@ -260,7 +260,7 @@ def test_errors_are_loud():
 @pytest.mark.parametrize("name,want", [
     ("dagnet_bsk_gat_n10", "register-resident"), ("avrnn_bsk_gat", "register-resident"), ("vrnn_bsk", "register-resident"),
     ("avrnn_sdd_gat", "register-resident"), ("vrnn_sdd", "register-resident"), ("avrnn_bsk_gat_L2_n10", "register-resident"),
-    ("dagnet_bsk_gat_ragged_1_32", "LDS-tiled"),      # n_max_agents = 32 > 16: disposition wider than one k-tile
+    ("dagnet_bsk_gat_ragged_1_32", "register-resident"),      # n_max_agents = 32: two disposition tiles (model code 4)
     ("avrnn_bsk_gat_n33", "LDS-tiled"),               # a 33-agent scene does not fit a 32-row wave tile
     ("dagnet_bsk_gcn_n10", "register-resident"), ("dagnet_tiny_gat_adj1", "LDS-tiled"), ("dagnet_sdd_gat_g960", "wide goal head"), ("dagnet_sdd_gcn_g960", "global scratch"),
 ])

@@ -613,8 +613,14 @@ void wide_pack(Packer &pk, const dagnet_config &c, WideWeights &W) {
             return (float)acc;
         },
         PF + 2 * P, G, W.hf_ld);
+    const Tensor *g = pk.get("graph_goals.bn1.weight", {G}), *b = pk.get("graph_goals.bn1.bias", {G});
+    const Tensor *mu = pk.get("graph_goals.bn1.running_mean", {G}), *var = pk.get("graph_goals.bn1.running_var", {G});
+    if (!g || !b || !mu || !var) return;
+    const float *gp = g->p, *bp = b->p, *mp = mu->p, *vp = var->p;
+    // out layer: the attention is applied to its 32-wide input first (wide_head.hip attn_mix_kernel), so eval BatchNorm folds
+    // into the dense layer: rows of Wout^T scaled by gamma / sqrt(var + eps), shift as the bias, tanh in the GEMM epilogue
     W.out_ld = pad4(PF);
-    W.out_w = pk.rowmajor([=](int n, int k) { return wo[(size_t)k * G + n]; }, G, PF, W.out_ld);
+    W.out_w = pk.rowmajor([=](int n, int k) { return wo[(size_t)k * G + n] * (gp[n] / sqrtf(vp[n] + 1e-5f)); }, G, PF, W.out_ld);
     W.fold_out = pk.vec(
         [=](int i) {
             const int dst = i / PF, k = i % PF;
@@ -623,17 +629,7 @@ void wide_pack(Packer &pk, const dagnet_config &c, WideWeights &W) {
             return (float)acc;
         },
         2 * PF, 2 * PF);
-    const Tensor *g = pk.get("graph_goals.bn1.weight", {G}), *b = pk.get("graph_goals.bn1.bias", {G});
-    const Tensor *mu = pk.get("graph_goals.bn1.running_mean", {G}), *var = pk.get("graph_goals.bn1.running_var", {G});
-    if (!g || !b || !mu || !var) return;
-    const float *gp = g->p, *bp = b->p, *mp = mu->p, *vp = var->p;
-    W.bn = pk.vec(
-        [=](int i) {
-            const int cidx = i % G;
-            const float sc = gp[cidx] / sqrtf(vp[cidx] + 1e-5f);
-            return i < G ? sc : bp[cidx] - mp[cidx] * sc;
-        },
-        2 * G, 2 * G);
+    W.bn = pk.vec([=](int i) { return bp[i] - mp[i] * (gp[i] / sqrtf(vp[i] + 1e-5f)); }, G, G);     // shift only
     W.lg_ld = 2 * pad4(G);
     const int Gp = pad4(G);
     W.lg_w = pk.rowmajor([=](int n, int k) { return k < Gp ? (k < G ? wl[(size_t)n * 2 * G + k] : 0.f)

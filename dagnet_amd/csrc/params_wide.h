@@ -11,9 +11,9 @@ struct WideWeights {            // float offsets into the model's weight buffer;
     int32_t g0_gather, g0_gld;  // dec_goal.0 one-hot columns, by goal  [G][g0_gld]
     int32_t g2_w, g2_ld, g2_b;  // dec_goal.2                           [G][pad4(H)], [G]
     int32_t hf_w, hf_ld;        // graph_goals heads + folded logits    [P*F + 2P][pad4(G)]
-    int32_t out_w, out_ld;      // graph_goals.out_att.W^T              [G][pad4(P*F)]
+    int32_t out_w, out_ld;      // graph_goals.out_att.W^T, rows scaled by the folded BatchNorm scale   [G][pad4(P*F)]
     int32_t fold_out;           // [2][P*F]: W_out . a_src, W_out . a_dst
-    int32_t bn;                 // [2][G]: folded eval BatchNorm scale, shift
+    int32_t bn;                 // [G]: folded eval BatchNorm shift (the bias of the out GEMM)
     int32_t lg_w, lg_ld, lg_b;  // lg_goals.0                           [G][pad4(2G)], [G]
 };
 
@@ -21,8 +21,8 @@ struct WideBuffers {            // workspace of one plan (rows = K*N)
     float *A0;                  // [rows][a0_ld]   [d | h_last]
     float *T1;                  // [rows][H]
     float *A1;                  // [rows][2*Gp]    [softmax(dec_goal) | graph_goals]   (Gp = pad4(G))
-    float *B;                   // [rows][Gp]      Wh of the out head, then the lg_goals logits
-    float *HS;                  // [rows][hs_ld]   heads (P*F) + folded logits (2P)
+    float *B;                   // [rows][Gp]      the lg_goals logits
+    float *HS;                  // [rows][hs_ld]   heads (P*F) + folded logits (2P); then X3 = out-layer attention over X2
     float *X2;                  // [rows][P*F]
     float *S2;                  // [rows][2]
     float *adj;                 // [K][compact]    block-diagonal adjacency of every sample

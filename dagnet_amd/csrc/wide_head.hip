@@ -7,8 +7,8 @@
 //   A1[:, :G] = softmax(T1 W2^T + b2)                     GEMM + wide_softmax_kernel
 //   HS = A1[:, :G] [heads | folded logits]^T              GEMM (N = P*F + 2P)
 //   X2 = elu(per-head attention), S2 = X2 fold_out^T      wide_attn_heads_kernel
-//   B  = X2 Wout^T                                        GEMM
-//   A1[:, G:] = tanh(bn(attention over B))                wide_attn_out_kernel
+//   X3 = out-layer attention applied to X2 (32 wide)      wide_attn_mix_kernel
+//   A1[:, G:] = tanh(bn(X3 Wout^T))                       GEMM (BatchNorm folded into Wout / bias, tanh epilogue)
 //   B  = A1 Wlg^T + blg                                   GEMM (K = 2G)
 //   goal = argmax_g exp(softmax(B)_g) / q_g               wide_draw_kernel
 // Teacher-forced pass (DAGNet.forward, models/dagnet/model.py:151-162): same layers with positions, previous goals and
@@ -27,7 +27,7 @@ extern "C" hipError_t dn_launch_adjacency(int type, double sigma, int top_k, con
 
 namespace wide {
 
-enum { ACT_NONE = 0, ACT_RELU = 3 };    // gemm_f32.hip
+enum { ACT_NONE = 0, ACT_TANH = 2, ACT_RELU = 3 };    // gemm_f32.hip
 
 // state of every (sample, row): the K samples start from the same h / position / goal
 __global__ void init_state_kernel(int N, int K, int L, int R, int G, const float *__restrict__ h0, const float *__restrict__ x0,
@@ -159,13 +159,14 @@ __global__ void attn_heads_kernel(int N, int K, const int32_t *__restrict__ scen
     }
 }
 
-// out head of graph_goals (concat=False) + eval BatchNorm + tanh (gat_model.py:18-22), one workgroup per
-// (sample, scene):  out_i = tanh(scale * sum_j a_ij B_j + shift), written to columns [dst_col0, dst_col0 + G) of A1
-__global__ __launch_bounds__(256) void attn_out_kernel(int N, int S, const int32_t *__restrict__ scene_ptr,
+// out head of graph_goals (concat=False, gat_model.py:18-22): the attention of the out layer is applied BEFORE its dense
+// layer -- sum_j a_ij (X2_j Wout) == (sum_j a_ij X2_j) Wout -- so the per-scene kernel mixes the PF-wide (32) head
+// outputs instead of the g_dim-wide products, and the GEMM that follows writes tanh(bn(.)) straight into A1[:, G:]
+// (BatchNorm scale folded into Wout's rows, shift as the bias, tanh in the epilogue).  One workgroup per (sample, scene).
+__global__ __launch_bounds__(256) void attn_mix_kernel(int N, int S, const int32_t *__restrict__ scene_ptr,
                                                        const int64_t *__restrict__ off_compact, int64_t compact, int64_t adj_ld,
                                                        const float *__restrict__ adj, const float *__restrict__ S2, float alpha,
-                                                       const float *__restrict__ B, int64_t ldb, int G,
-                                                       const float *__restrict__ bn, float *__restrict__ out, int64_t ldo) {
+                                                       const float *__restrict__ X2, int PF, float *__restrict__ X3, int64_t ld3) {
     __shared__ float att[32][33];
     const int u = blockIdx.x, k = u / S, s = u - k * S;
     const int b = scene_ptr[s], n = scene_ptr[s + 1] - b;      // n <= 32 (checked by the host)
@@ -191,31 +192,11 @@ __global__ __launch_bounds__(256) void attn_out_kernel(int N, int S, const int32
         for (int j = 0; j < n; ++j) att[tid][j] *= inv;
     }
     __syncthreads();
-    const int G4 = G >> 2;                                       // G is a multiple of 4 (checked by the host)
-    for (int c4 = tid; c4 < G4; c4 += 256) {
-        const float4 sc = *reinterpret_cast<const float4 *>(bn + c4 * 4);
-        const float4 sh = *reinterpret_cast<const float4 *>(bn + G + c4 * 4);
-        for (int i0 = 0; i0 < n; i0 += 8) {
-            float4 acc[8];
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii) acc[ii] = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int j = 0; j < n; ++j) {
-                const float4 bj = *reinterpret_cast<const float4 *>(B + (r0 + j) * ldb + c4 * 4);
-#pragma unroll
-                for (int ii = 0; ii < 8; ++ii) {
-                    const float w = att[min(i0 + ii, 31)][j];
-                    acc[ii].x += w * bj.x; acc[ii].y += w * bj.y; acc[ii].z += w * bj.z; acc[ii].w += w * bj.w;
-                }
-            }
-#pragma unroll
-            for (int ii = 0; ii < 8; ++ii)
-                if (i0 + ii < n) {
-                    float4 o;
-                    o.x = tanhf(acc[ii].x * sc.x + sh.x); o.y = tanhf(acc[ii].y * sc.y + sh.y);
-                    o.z = tanhf(acc[ii].z * sc.z + sh.z); o.w = tanhf(acc[ii].w * sc.w + sh.w);
-                    *reinterpret_cast<float4 *>(out + (r0 + i0 + ii) * ldo + c4 * 4) = o;
-                }
-        }
+    for (int e = tid; e < n * PF; e += 256) {
+        const int i = e / PF, f = e - i * PF;
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) acc += att[i][j] * X2[(r0 + j) * PF + f];
+        X3[(r0 + i) * ld3 + f] = acc;
     }
 }
 
@@ -376,11 +357,12 @@ extern "C" hipError_t dn_wide_goal_head(const WideStep *sp, hipStream_t st) {
                            s.alpha, s.b.X2, s.b.S2);
         W_TRY(hipGetLastError());
     }
-    W_TRY(dn_gemm_nt_gather(s.b.X2, PF, s.wp + s.w.out_w, s.w.out_ld, nullptr, s.b.B, Gp, rows, s.G, PF, wide::ACT_NONE, 0.f,
-                            nullptr, nullptr, 0, st));
-    hipLaunchKernelGGL(wide::attn_out_kernel, dim3((unsigned)(s.K * s.S)), dim3(256), 0, st, s.N, s.S, s.scene_ptr, adj_off,
-                       s.compact, adj_ld, adj, s.b.S2, s.alpha, s.b.B, Gp, s.G, s.wp + s.w.bn, s.b.A1 + Gp, 2 * Gp);
+    // X3 reuses the HS buffer (dead after attn_heads): [rows][hs_ld], first PF columns
+    hipLaunchKernelGGL(wide::attn_mix_kernel, dim3((unsigned)(s.K * s.S)), dim3(256), 0, st, s.N, s.S, s.scene_ptr, adj_off, s.compact,
+                       adj_ld, adj, s.b.S2, s.alpha, s.b.X2, PF, s.b.HS, s.b.hs_ld);
     W_TRY(hipGetLastError());
+    W_TRY(dn_gemm_nt_gather(s.b.HS, s.b.hs_ld, s.wp + s.w.out_w, s.w.out_ld, s.wp + s.w.bn, s.b.A1 + Gp, 2 * Gp, rows, s.G, PF,
+                            wide::ACT_TANH, 0.f, nullptr, nullptr, 0, st));
     W_TRY(dn_gemm_nt_gather(s.b.A1, 2 * Gp, s.wp + s.w.lg_w, s.w.lg_ld, s.wp + s.w.lg_b, s.b.B, Gp, rows, s.G, (int)(2 * Gp),
                             wide::ACT_NONE, 0.f, nullptr, nullptr, 0, st));
     if (teacher)

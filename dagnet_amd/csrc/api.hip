@@ -90,8 +90,9 @@ struct dagnet_model {
     size_t wp_floats = 0;
     int device = 0;
     bool v2 = false;            // the register-resident kernel (rollout_v2.hip) covers this model
-    V2Weights w2;
+    V2Weights w2;               // absolute offsets into d_wp (forward_v2.hip reads this table)
     V2Weights *d_w2 = nullptr;  // device copy of w2
+    int v2_base = 0;            // start of the v2 region in d_wp: rollout_v2.hip uses compile-time offsets relative to it
     // wide goal head (wide_head.hip) + register-resident kernel model 3 for the rest of the step
     bool wide = false;
     WideWeights ww;
@@ -209,10 +210,10 @@ struct Packer {
         for (int i = 0; i < n; ++i) buf[off + i] = f(i);
         return off;
     }
-    int gather(const WFn &W, int N, int G) {
+    int gather(const WFn &W, int N, int G, int Gpad = 0) {      // Gpad: rows allocated (zero beyond G)
         const int ld = pad32(N);
         const int off = align();
-        buf.resize(off + (size_t)G * ld, 0.f);
+        buf.resize(off + (size_t)std::max(G, Gpad) * ld, 0.f);
         for (int g = 0; g < G; ++g)
             for (int n = 0; n < N; ++n) buf[off + (size_t)g * ld + n] = W(n, g);
         return off;
@@ -408,7 +409,10 @@ DnGru pack_gru(Packer &pk, int l, int R, int H) {
 }
 
 // ---- register-resident kernel (rollout_v2.hip): same tensors, MFMA-chain packing -------------
-V2Lin v2_linear(Packer &pk, const std::string &name, int N, int Ktot, std::vector<SegSpec> segs, int gcol0 = -1, int G = 0) {
+// Npad / Gpad / SegSpec.kpad: sizes the segment is padded to (zeros), so that the layout of an instantiation does not
+// depend on g_dim or n_max_agents (params_v2.h v2_layout)
+V2Lin v2_linear(Packer &pk, const std::string &name, int N, int Ktot, std::vector<SegSpec> segs, int gcol0 = -1, int G = 0,
+                int Npad = 0, int Gpad = 0) {
     V2Lin L;
     L.w[0] = L.w[1] = L.w[2] = 0;
     L.bias = L.gather = -1;
@@ -416,13 +420,15 @@ V2Lin v2_linear(Packer &pk, const std::string &name, int N, int Ktot, std::vecto
     const Tensor *B = pk.get(name + ".bias", {N});
     if (!W || !B) return L;
     const float *w = W->p, *b = B->p;
+    const int Np = std::max(N, Npad);
     for (size_t s = 0; s < segs.size(); ++s) {
         const int c0 = segs[s].col0;
         const int Ks = segs[s].K;
-        L.w[s] = pk.chain([=](int n, int k) { return k < Ks ? w[(size_t)n * Ktot + c0 + k] : 0.f; }, N, std::max(Ks, segs[s].kpad));
+        L.w[s] = pk.chain([=](int n, int k) { return (n < N && k < Ks) ? w[(size_t)n * Ktot + c0 + k] : 0.f; }, Np, std::max(Ks, segs[s].kpad));
     }
-    L.bias = pk.vec([=](int n) { return b[n]; }, N, pad32(N));
-    if (gcol0 >= 0) L.gather = pk.gather([=](int n, int g) { return w[(size_t)n * Ktot + gcol0 + g]; }, N, G);
+    L.bias = pk.vec([=](int n) { return b[n]; }, N, pad32(Np));
+    // one-hot input: row g of the table = column gcol0 + g of the weight PLUS the bias (v2_common.h finish<> loads one row)
+    if (gcol0 >= 0) L.gather = pk.gather([=](int n, int g) { return w[(size_t)n * Ktot + gcol0 + g] + b[n]; }, N, G, Gpad);
     return L;
 }
 
@@ -439,7 +445,8 @@ V2Lin v2_pair(Packer &pk, const std::string &a, const std::string &b, int Z, int
     return L;
 }
 
-V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, int P) {
+// pad: nin and nout are padded to this many features (the goal graph: V2_GT tiles whatever g_dim is)
+V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, int P, int pad = 0) {
     V2Gat g;
     memset(&g, 0, sizeof(g));
     g.nout = nout;
@@ -455,17 +462,19 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     const Tensor *ao = pk.get(prefix + ".out_att.a", {2 * nout, 1});
     if (!Wo || !ao) return g;
     const float *wo = Wo->p, *aop = ao->p;
-    g.heads = pk.chain([=](int n, int k) { return Wh[n / F][(size_t)k * F + (n % F)]; }, P * F, nin);
+    const int ninp = std::max(nin, pad), noutp = std::max(nout, pad);
+    g.heads = pk.chain([=](int n, int k) { return k < nin ? Wh[n / F][(size_t)k * F + (n % F)] : 0.f; }, P * F, ninp);
     // a . (x W) == x . (W a): the attention logits' two dot products become 2P extra output features
     g.fold = pk.chain(
         [=](int q, int k) {
             const int p = q % P, half = q / P;
             double acc = 0.0;
+            if (k >= nin) return 0.f;
             for (int f = 0; f < F; ++f) acc += (double)Wh[p][(size_t)k * F + f] * (double)ah[p][half * F + f];
             return (float)acc;
         },
-        2 * P, nin);
-    g.out = pk.chain([=](int n, int k) { return wo[(size_t)k * nout + n]; }, nout, P * F);
+        2 * P, ninp);
+    g.out = pk.chain([=](int n, int k) { return n < nout ? wo[(size_t)k * nout + n] : 0.f; }, noutp, P * F);
     g.fold_out = pk.chain(
         [=](int q, int k) {
             double acc = 0.0;
@@ -477,7 +486,7 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     const Tensor *mu = pk.get(prefix + ".bn1.running_mean", {nout}), *var = pk.get(prefix + ".bn1.running_var", {nout});
     if (!ga || !be || !mu || !var) return g;
     const float *gp = ga->p, *bp = be->p, *mp = mu->p, *vp = var->p;
-    const int ld = pad32(nout);
+    const int ld = pad32(noutp);
     // eval-mode BatchNorm folded to y = x * scale + shift
     g.bn = pk.vec(
         [=](int i) {
@@ -492,7 +501,7 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
 
 // GCN in the V2Gat slots (v2_common.h gcn<>): heads = W1, fold = layer-1 scale|shift, out = W2, bn = layer-2 scale|shift;
 // bias and eval BatchNorm folded: y = agg * sc + ((b - mean) * sc + beta), sc = gamma / sqrt(var + eps)
-V2Gat v2_gcn(Packer &pk, const std::string &prefix, int nin, int nout, int F) {
+V2Gat v2_gcn(Packer &pk, const std::string &prefix, int nin, int nout, int F, int pad = 0) {
     V2Gat g;
     memset(&g, 0, sizeof(g));
     g.nout = nout;
@@ -502,8 +511,9 @@ V2Gat v2_gcn(Packer &pk, const std::string &prefix, int nin, int nout, int F) {
     const float *b1 = nullptr, *b2 = nullptr;
     if (pk.has(prefix + ".gc1.bias")) { const Tensor *b = pk.get(prefix + ".gc1.bias", {F}); if (b) b1 = b->p; }
     if (pk.has(prefix + ".gc2.bias")) { const Tensor *b = pk.get(prefix + ".gc2.bias", {nout}); if (b) b2 = b->p; }
-    g.heads = pk.chain([=](int n, int k) { return w1[(size_t)k * F + n]; }, F, nin);
-    g.out = pk.chain([=](int n, int k) { return w2[(size_t)k * nout + n]; }, nout, F);
+    const int ninp = std::max(nin, pad), noutp = std::max(nout, pad);
+    g.heads = pk.chain([=](int n, int k) { return k < nin ? w1[(size_t)k * F + n] : 0.f; }, F, ninp);
+    g.out = pk.chain([=](int n, int k) { return n < nout ? w2[(size_t)k * nout + n] : 0.f; }, noutp, F);
     auto fold = [&](const std::string &bn, int n, const float *bias, int ld) {
         const Tensor *ga = pk.get(bn + ".weight", {n}), *be = pk.get(bn + ".bias", {n});
         const Tensor *mu = pk.get(bn + ".running_mean", {n}), *var = pk.get(bn + ".running_var", {n});
@@ -519,7 +529,7 @@ V2Gat v2_gcn(Packer &pk, const std::string &prefix, int nin, int nout, int F) {
             2 * ld, 2 * ld);
     };
     g.fold = fold(prefix + ".bn1", F, b1, 32);
-    g.bn = fold(prefix + ".bn2", nout, b2, pad32(nout));
+    g.bn = fold(prefix + ".bn2", nout, b2, pad32(noutp));
     return g;
 }
 
@@ -642,6 +652,8 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
     memset(&W, 0, sizeof(W));
     const int H = 64, R = 64, Z = c.z_dim, G = c.g_dim, Dd = 2 * c.n_max_agents;
     const bool dag = c.model == DAGNET_MODEL_DAGNET, graph = c.model != DAGNET_MODEL_VRNN;
+    const int GP = V2_GT * 32;                       // goal-wide dims are padded to V2_GT tiles
+    const int DP = (ext || Dd > 32) ? 64 : 32;       // disposition tiles
     DnRaw px0 = pack_raw_linear(pk, "phi_x.0", H, 2), dm = pack_raw_linear(pk, "dec_mean", 2, H);
     W.phi_x0_w = px0.w; W.phi_x0_b = px0.b;
     W.dec_mean_w = dm.w; W.dec_mean_b = dm.b;
@@ -649,9 +661,9 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
     W.phi_z0 = v2_linear(pk, "phi_z.0", H, Z, {{0, Z}});
     W.phi_z2 = v2_linear(pk, "phi_z.2", H, H, {{0, H}});
     if (dag) {
-        W.prior0 = v2_linear(pk, "prior.0", H, G + R, {{G, R}}, 0, G);
+        W.prior0 = v2_linear(pk, "prior.0", H, G + R, {{G, R}}, 0, G, 0, GP);
         // model 3 multiplies two disposition tiles whatever n_max_agents is
-        W.dec0 = v2_linear(pk, "dec.0", H, Dd + G + H + R, {{0, Dd, (ext || Dd > 32) ? 64 : 0}, {Dd + G, H}, {Dd + G + H, R}}, Dd, G);
+        W.dec0 = v2_linear(pk, "dec.0", H, Dd + G + H + R, {{0, Dd, DP}, {Dd + G, H}, {Dd + G + H, R}}, Dd, G, 0, GP);
     } else {
         W.prior0 = v2_linear(pk, "prior.0", H, R, {{0, R}});
         W.dec0 = v2_linear(pk, "dec.0", H, H + R, {{0, H}, {H, R}});
@@ -659,7 +671,7 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
     W.prior2 = v2_linear(pk, "prior.2", H, H, {{0, H}});
     W.prior_ml = v2_pair(pk, "prior_mean", "prior_logvar", Z, H);
     {               // teacher-forced pass (forward_v2.hip)
-        if (dag) W.enc0 = v2_linear(pk, "enc.0", H, H + G + R, {{0, H}, {H + G, R}}, H, G);
+        if (dag) W.enc0 = v2_linear(pk, "enc.0", H, H + G + R, {{0, H}, {H + G, R}}, H, G, 0, GP);
         else W.enc0 = v2_linear(pk, "enc.0", H, H + R, {{0, H}, {H, R}});
         W.enc2 = v2_linear(pk, "enc.2", H, H, {{0, H}});
         W.enc_ml = v2_pair(pk, "enc_mean", "enc_logvar", Z, H);
@@ -674,12 +686,28 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
         W.blend = v2_linear(pk, dag ? "lg_hiddens" : "lg", R, 2 * R, {{0, R}, {R, R}});
     }
     if (dag && !ext) {
-        W.dec_goal0 = v2_linear(pk, "dec_goal.0", H, Dd + R + G, {{0, Dd, Dd > 32 ? 64 : 0}, {Dd, R}}, Dd + R, G);
-        W.dec_goal2 = v2_linear(pk, "dec_goal.2", G, H, {{0, H}});
-        W.g_goal = c.graph_model == DAGNET_GRAPH_GCN ? v2_gcn(pk, "graph_goals", G, G, c.graph_hid)
-                                                     : v2_gat(pk, "graph_goals", G, G, c.graph_hid, c.n_heads);
-        W.lg_goals = v2_linear(pk, "lg_goals.0", G, 2 * G, {{0, G}, {G, G}});
+        W.dec_goal0 = v2_linear(pk, "dec_goal.0", H, Dd + R + G, {{0, Dd, DP}, {Dd, R}}, Dd + R, G, 0, GP);
+        W.dec_goal2 = v2_linear(pk, "dec_goal.2", G, H, {{0, H}}, -1, 0, GP);
+        W.g_goal = c.graph_model == DAGNET_GRAPH_GCN ? v2_gcn(pk, "graph_goals", G, G, c.graph_hid, GP)
+                                                     : v2_gat(pk, "graph_goals", G, G, c.graph_hid, c.n_heads, GP);
+        W.lg_goals = v2_linear(pk, "lg_goals.0", G, 2 * G, {{0, G, GP}, {G, G, GP}}, -1, 0, GP);
     }
+}
+
+
+// The packer's table against the compile-time layout of the instantiation that will run (params_v2.h v2_layout):
+// every offset the layout marks as used must equal base + the layout's relative offset.  Returns a description of the
+// first difference, or an empty string.
+std::string v2_check_layout(const V2Weights &W, int base, int total, int model_code, int nl, int zd, int gm) {
+    const V2Layout L = v2_layout(model_code, nl, zd, gm);
+    const int32_t *a = reinterpret_cast<const int32_t *>(&W), *o = reinterpret_cast<const int32_t *>(&L.off),
+                  *u = reinterpret_cast<const int32_t *>(&L.used);
+    for (size_t i = 0; i < sizeof(V2Weights) / sizeof(int32_t); ++i)
+        if (u[i] && a[i] != base + o[i])
+            return "v2 layout: table entry " + std::to_string(i) + " is at " + std::to_string(a[i] - base) + ", layout says " +
+                   std::to_string(o[i]);
+    if (total != L.total) return "v2 layout: region holds " + std::to_string(total) + " floats, layout says " + std::to_string(L.total);
+    return "";
 }
 
 }   // namespace
@@ -777,11 +805,21 @@ extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor
     }
     }
     m->v2 = v2_eligible(c);
-    if (m->v2 && pk.missing.empty()) v2_pack(pk, c, m->w2);
     m->wide = !m->v2 && wide_eligible(c) && !getenv("DAGNET_NO_WIDE");
-    if (m->wide && pk.missing.empty()) {
-        v2_pack(pk, c, m->w2, true);
-        wide_pack(pk, c, m->ww);
+    if ((m->v2 || m->wide) && pk.missing.empty()) {
+        m->v2_base = pk.align();
+        v2_pack(pk, c, m->w2, m->wide);
+        if (pk.missing.empty() && !m->wide) {      // (model 3 reads the table: its one-hot tables have g_dim rows)
+            const int code = dag && Dd > 32 ? 4 : c.model;
+            const std::string bad = v2_check_layout(m->w2, m->v2_base, pk.align() - m->v2_base, code, c.n_layers, c.z_dim,
+                                                    c.graph_model == DAGNET_GRAPH_GCN ? 2 : 1);
+            if (!bad.empty()) {
+                const int rc = fail(DAGNET_ERR_INVALID, "internal error, %s", bad.c_str());
+                delete m;
+                return rc;
+            }
+        }
+        if (m->wide) wide_pack(pk, c, m->ww);
     }
     if (!pk.missing.empty()) {
         const int rc = fail(DAGNET_ERR_MISSING, "state dict entry missing or mis-shaped: %s", pk.missing.c_str());
@@ -1115,7 +1153,7 @@ extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_
     if (m->v2 && p->n_tiles2 > 0 && !getenv("DAGNET_FORCE_GENERIC")) {
         V2Run r;
         memset(&r, 0, sizeof(r));
-        r.wp = m->d_wp;
+        r.wp = m->d_wp + m->v2_base;      // rollout_v2: compile-time offsets relative to the v2 region
         r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
         r.S = p->S; r.N = p->N; r.K = p->K; r.T = T; r.n_tiles = p->n_tiles2;
         r.G = m->dims.G; r.D = m->dims.D; r.adj_type = m->dims.adj_type;
@@ -1145,7 +1183,7 @@ extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_
         ws.q = d_q; ws.force_goals = d_force_goals; ws.seed = seed; ws.out_goals = d_out_goals;
         V2Run r;
         memset(&r, 0, sizeof(r));
-        r.wp = m->d_wp;
+        r.wp = m->d_wp;                    // model 3: absolute offsets from the table
         r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
         r.S = p->S; r.N = p->N; r.K = p->K; r.T = T; r.n_tiles = p->n_tiles2;
         r.G = D.G; r.D = D.D; r.adj_type = D.adj_type; r.alpha = D.alpha; r.sigma = D.sigma;

@@ -11,7 +11,7 @@
 struct V2Lin {
     int32_t w[3];      // float offsets of up to 3 chain-packed segments
     int32_t bias;      // [NT*32] zero padded, -1 = none
-    int32_t gather;    // one-hot table [G][NT*32], -1 = none
+    int32_t gather;    // one-hot table [G][NT*32] with the bias folded into every row, -1 = none
 };
 
 // GCN models reuse the slots (api.hip v2_gcn, v2_common.h gcn<>): heads = W1, fold = [2][32] layer-1 scale | shift,
@@ -47,8 +47,106 @@ struct V2Weights {
     int32_t dec_logvar_w, dec_logvar_b;   // raw [2][H], [2]
 };
 
+// ---------------------------------------------------------------------------------------------
+// Compile-time layout.  For one kernel instantiation every segment size is known (goal-wide dims are padded to
+// V2_GT tiles, the disposition to its tile count), so the offsets of V2Weights RELATIVE to the start of the v2
+// region are constants: the rollout kernel uses them as immediates (no table loads on the critical path, no
+// SGPRs held for offsets).  v2_layout() mirrors the order of api.hip v2_pack(); dagnet_model_create() compares the
+// packer's table with it and refuses the model on any difference.
+// model codes as in rollout_v2.hip: 0 VRNN, 1 A-VRNN, 2 DAG-Net, 3 DAG-Net with the goal head outside, 4 DAG-Net with
+// two disposition tiles.  gm: 1 GAT, 2 GCN.
+// ---------------------------------------------------------------------------------------------
+#define V2_GT 3     // goal tiles (g_dim <= 96)
+
+struct V2Layout {
+    V2Weights off;      // relative float offsets
+    V2Weights used;     // 1 where `off` holds an offset this instantiation packs
+    int32_t total;      // floats in the v2 region
+};
+
+constexpr V2Layout v2_layout(int model, int nl, int zd, int gm) {
+    V2Layout L{};
+    int32_t cur = 0;
+    const bool dag = model >= 2, graph = model != 0, head = model == 2 || model == 4;
+    const int DT = (model == 3 || model == 4) ? 2 : 1, GT = V2_GT, GP = V2_GT * 32;
+    const int zt2 = (2 * zd + 31) / 32;
+    auto take = [&cur](int32_t &o, int32_t &u, int n) {
+        cur = (cur + 3) & ~3;
+        o = cur;
+        u = 1;
+        cur += n;
+    };
+    // dense layer: chain segments [nt][k_i] (k_i = 0: absent), bias [nt*32], optional one-hot table [GP][nt*32]
+    auto lin = [&](V2Lin &o, V2Lin &u, int nt, int k0, int k1, int k2, bool gather) {
+        o.bias = -1;
+        o.gather = -1;
+        if (k0) take(o.w[0], u.w[0], nt * k0 * 1024);
+        if (k1) take(o.w[1], u.w[1], nt * k1 * 1024);
+        if (k2) take(o.w[2], u.w[2], nt * k2 * 1024);
+        take(o.bias, u.bias, nt * 32);
+        if (gather) take(o.gather, u.gather, GP * nt * 32);
+    };
+    auto raw = [&](int32_t &w, int32_t &uw, int32_t &b, int32_t &ub, int nw, int nb) {
+        take(w, uw, nw);
+        take(b, ub, nb);
+    };
+    auto graphnet = [&](V2Gat &o, V2Gat &u, int kt, int nt) {
+        if (gm == 2) {      // GCN: heads = W1, out = W2, fold / bn = folded scale | shift of the two layers
+            take(o.heads, u.heads, kt * 1024);
+            take(o.out, u.out, nt * 1024);
+            take(o.fold, u.fold, 64);
+            take(o.bn, u.bn, 2 * nt * 32);
+        } else {
+            take(o.heads, u.heads, kt * 1024);
+            take(o.fold, u.fold, kt * 1024);
+            take(o.out, u.out, nt * 1024);
+            take(o.fold_out, u.fold_out, 1024);
+            take(o.bn, u.bn, 2 * nt * 32);
+        }
+    };
+    raw(L.off.phi_x0_w, L.used.phi_x0_w, L.off.phi_x0_b, L.used.phi_x0_b, 128, 64);
+    raw(L.off.dec_mean_w, L.used.dec_mean_w, L.off.dec_mean_b, L.used.dec_mean_b, 128, 2);
+    lin(L.off.phi_x2, L.used.phi_x2, 2, 2, 0, 0, false);
+    lin(L.off.phi_z0, L.used.phi_z0, 2, (zd + 31) / 32, 0, 0, false);
+    lin(L.off.phi_z2, L.used.phi_z2, 2, 2, 0, 0, false);
+    if (dag) {
+        lin(L.off.prior0, L.used.prior0, 2, 2, 0, 0, true);
+        lin(L.off.dec0, L.used.dec0, 2, DT, 2, 2, true);
+    } else {
+        lin(L.off.prior0, L.used.prior0, 2, 2, 0, 0, false);
+        lin(L.off.dec0, L.used.dec0, 2, 2, 2, 0, false);
+    }
+    lin(L.off.prior2, L.used.prior2, 2, 2, 0, 0, false);
+    lin(L.off.prior_ml, L.used.prior_ml, zt2, 2, 0, 0, false);
+    lin(L.off.enc0, L.used.enc0, 2, 2, 2, 0, dag);
+    lin(L.off.enc2, L.used.enc2, 2, 2, 0, 0, false);
+    lin(L.off.enc_ml, L.used.enc_ml, zt2, 2, 0, 0, false);
+    raw(L.off.dec_logvar_w, L.used.dec_logvar_w, L.off.dec_logvar_b, L.used.dec_logvar_b, 128, 2);
+    lin(L.off.dec2, L.used.dec2, 2, 2, 0, 0, false);
+    for (int l = 0; l < nl; ++l) {
+        const int kx = l == 0 ? 4 : 2;
+        lin(L.off.gru[l].r, L.used.gru[l].r, 2, kx, 2, 0, false);
+        lin(L.off.gru[l].z, L.used.gru[l].z, 2, kx, 2, 0, false);
+        lin(L.off.gru[l].ni, L.used.gru[l].ni, 2, kx, 0, 0, false);
+        lin(L.off.gru[l].nh, L.used.gru[l].nh, 2, 2, 0, 0, false);
+    }
+    if (graph) {
+        graphnet(L.off.g_hid, L.used.g_hid, 2, 2);
+        lin(L.off.blend, L.used.blend, 2, 2, 2, 0, false);
+    }
+    if (head) {
+        lin(L.off.dec_goal0, L.used.dec_goal0, 2, DT, 2, 0, true);
+        lin(L.off.dec_goal2, L.used.dec_goal2, GT, 2, 0, 0, false);
+        graphnet(L.off.g_goal, L.used.g_goal, GT, GT);
+        lin(L.off.lg_goals, L.used.lg_goals, GT, GT, GT, 0, false);
+    }
+    L.total = (cur + 3) & ~3;
+    return L;
+}
+
 struct V2Run {
-    const float *wp;                 // chain-packed weights
+    const float *wp;                 // chain-packed weights: start of the buffer (forward_v2: absolute offsets from the table)
+                                     // or of its v2 region (rollout_v2: compile-time relative offsets, v2_layout())
     const int32_t *scene_ptr, *tile_u0, *tile_nu;
     int32_t S, N, K, T, n_tiles;
     int32_t G, D, adj_type;

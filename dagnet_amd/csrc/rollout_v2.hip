@@ -29,7 +29,11 @@ namespace v2 {
 // GM: 1 = GAT (4 heads x 8), 2 = GCN (graph_hid <= 32).
 template <int MODEL, int NL, int ZD, int GM>
 __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
-    const V2Weights &W = *Wp;     // offsets are fetched with scalar loads where they are used (no SGPR residency)
+    // segment offsets are compile-time constants of the instantiation (params_v2.h v2_layout; checked against the packer's
+    // table when the model is created): immediates, no table loads on the critical path, no SGPRs held for them
+    // (model 3 keeps the packer's table: its one-hot tables have g_dim rows, in the hundreds)
+    static constexpr V2Layout LO = v2_layout(MODEL, NL, ZD, GM);
+    const V2Weights &W = MODEL == 3 ? *Wp : LO.off;
     __shared__ float xch[32 * 4 + 64];
     // DAG-Net: hidden state parked in LDS while the goal head needs the registers ([tile][reg][lane], conflict free)
     // also (NL == 2): the top layer's state is parked while GRU layer 0 runs (its 4 input tiles + 2 state tiles + gate
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     WBuf wp;
     wp.init(R.wp);
     constexpr bool DAG = MODEL >= 2, GRAPH = MODEL != 0, HEAD = MODEL == 2 || MODEL == 4, EXT = MODEL == 3;
-    constexpr int GT = 3;                   // goal tiles (g_dim <= 96)
+    constexpr int GT = V2_GT;               // goal tiles (g_dim <= 96)
     constexpr int DT = (EXT || MODEL == 4) ? 2 : 1;         // disposition tiles (2 * n_max_agents <= 32 * DT)
     const int t_begin = EXT ? R.t_begin : 0, t_end = EXT ? R.t_end : R.T;
 

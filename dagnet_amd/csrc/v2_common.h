@@ -56,7 +56,8 @@ __device__ __forceinline__ float ftanh(float x) {
     const float xc = fminf(fmaxf(x, -15.f), 15.f);
     return 1.0f - 2.0f * frcp(1.0f + fexp(2.0f * xc));
 }
-__device__ __forceinline__ float lrelu(float v, float s) { return fmaxf(v, v * s); }     // 0 < s < 1
+// 0 < s < 1: max(v, s v) as one v_med3_f32 (fmaxf would first canonicalise v: a third instruction per element)
+__device__ __forceinline__ float lrelu(float v, float s) { return __builtin_amdgcn_fmed3f(v, v * s, INFINITY); }
 __device__ __forceinline__ float sigm(float v) { return frcp(1.0f + fexp(-v)); }
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 __device__ __forceinline__ int xhalf(int v) { return __shfl_xor(v, 32); }
@@ -146,15 +147,21 @@ __device__ __forceinline__ void add_vec(T16 (&x)[NT], const WBuf &wp, int off, i
 
 // ACT: 0 none, 1 LeakyReLU(0.01), 2 ReLU
 template <int ACT, int NT>
-__device__ __forceinline__ void finish(T16 (&x)[NT], const WBuf &wp, const V2Lin &L, int gsel, int lh) {
-    if (L.bias >= 0) add_vec<NT>(x, wp, L.bias, 0, lh);
-    if (L.gather >= 0) add_vec<NT>(x, wp, L.gather, gsel * (NT * 32 * 4), lh);
+__device__ __forceinline__ void activate(T16 (&x)[NT]) {
     if (ACT != 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[nt][r] = ACT == 1 ? lrelu(x[nt][r], 0.01f) : fmaxf(x[nt][r], 0.f);
     }
+}
+// Bias of a dense layer, or - for a layer with a one-hot input - row gsel of its table (api.hip v2_linear: the
+// bias is folded into every row of the table), so either way ONE set of NT*4 independent loads per layer.
+template <int ACT, int NT>
+__device__ __forceinline__ void finish(T16 (&x)[NT], const WBuf &wp, const V2Lin &L, int gsel, int lh) {
+    const bool g = L.gather >= 0;
+    add_vec<NT>(x, wp, g ? L.gather : L.bias, g ? gsel * (NT * 32 * 4) : 0, lh);
+    activate<ACT, NT>(x);
 }
 
 // softmax over the first G features of an S-layout row (features >= G are set to 0)

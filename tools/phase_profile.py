@@ -1,7 +1,7 @@
 """Per-phase cycle breakdown of one tile of the rollout kernel (diagnostic build with -DDN_PROFILE).
 
     make -C dagnet_amd/csrc ../_lib/libdagnet_hip_prof.so
-    python tools/phase_profile.py [workload]
+    python tools/phase_profile.py [workload [scenes]]      (scenes * K / 3 <= 1024 tiles: one wave per SIMD)
 """
 import ctypes
 import os
@@ -25,7 +25,7 @@ def main():
     dev = torch.device("cuda", 0)
     a, model = bench.build(wl, dev)
     from dagnet_amd import synthetic as syn
-    S, n, K, T = 512, wl["agents"], wl["K"], wl["pred"]
+    S, n, K, T = (int(sys.argv[2]) if len(sys.argv) > 2 else 512), wl["agents"], wl["K"], wl["pred"]
     obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = [t.to(dev) for t in syn.make_batch([n] * S, wl["obs"], T, 5)]
     h = (torch.rand(a.n_layers, S * n, a.rnn_dim, device=dev) - 0.5)
     prof = torch.zeros(16, dtype=torch.int64, device=dev)

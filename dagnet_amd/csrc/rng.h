@@ -13,8 +13,10 @@
 __device__ __forceinline__ uint4 philox4x32(uint4 c, uint2 k) {
 #pragma unroll
     for (int i = 0; i < DN_PHILOX_ROUNDS; ++i) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        // one 32x32->64 product each (v_mad_u64_u32) instead of a v_mul_hi_u32 / v_mul_lo_u32 pair: integer
+        // multiplies are quarter rate and sit on the critical VALU path of the goal draw
+        const uint64_t p0 = (uint64_t)c.x * 0xD2511F53ull, p1 = (uint64_t)c.z * 0xCD9E8D57ull;
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
         k.x += 0x9E3779B9u;
         k.y += 0xBB67AE85u;

@@ -45,7 +45,7 @@ def main():
     tot = p.sum()
     for i, name in enumerate(PHASES):
         print(f"{name:32s} {p[i] / T:12.0f} ticks/step  {100 * p[i] / tot:5.1f}%")
-    print(f"{'total':32s} {tot / T:12.0f} ticks/step (clock64 = s_memtime, 100 MHz ticks)")
+    print(f"{'total':32s} {tot / T:12.0f} ticks/step (clock64 = s_memtime: shader clock cycles)")
 
 
 if __name__ == "__main__":

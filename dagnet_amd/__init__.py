@@ -4,6 +4,7 @@
     from dagnet_amd.adjacency_matrix import compute_adjs_distsim
     from dagnet_amd.utils import relative_to_abs, average_displacement_error
     from dagnet_amd.evaluate import evaluate
+    from dagnet_amd import data, loop          # loaders' batch layout; train / validate / test epoch functions
 
 The compute path is libdagnet_hip.so (dagnet_amd/csrc, include/dagnet_hip.h); there is no CPU fallback.
 """

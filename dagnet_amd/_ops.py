@@ -659,6 +659,9 @@ class ClipAdam:
         for p, m, v in live:
             _check(lib.dagnet_op_adam(p.numel(), _p(p.data), _p(p.grad), _p(m), _p(v), _p(self.sumsq), float(self.clip or 0.0), self.lr,
                                       self.betas[0], self.betas[1], self.eps, self.step_count, st))
+            # the kernel wrote through the raw pointer: tell autograd, and the modules' packed-weight cache
+            # (_runtime.HipBacked._fingerprint keys on the version counters), that the parameter changed
+            torch.autograd.graph.increment_version(p)
 
     def total_norm(self) -> torch.Tensor:
         return self.sumsq.sqrt().float()

@@ -277,10 +277,65 @@ def train_cases():
     train_case("train_dagnet_bsk_gat_n5", "dagnet", dict(REAL, n_layers=2), [5, 5, 5], 3, 4, 65)
 
 
+def data_case():
+    """Row L / 8(f) rank 2: the reference's collate functions and goal grid (models/dagnet/data/loader_bsk.py:12-35,
+    loader_sdd.py:16-42, models/utils/utils.py:210-233) on seeded inputs.  Inputs are stored with the outputs (small)."""
+    from models.dagnet.data import loader_bsk as ref_bsk
+    from models.dagnet.data import loader_sdd as ref_sdd
+    rng = np.random.default_rng(77)
+    out = {}
+    # goal grid: positions inside the rectangle, on grid lines, on the upper border (index = n_cells: the reference's quirk)
+    lim = (-3.0, 57.0, 2.0, 62.0)
+    tj = rng.uniform([lim[0], lim[2]], [lim[1], lim[3]], size=(6, 20, 2))
+    tj[0, 3] = [lim[0], lim[2]]
+    tj[1, 7] = [lim[1], lim[3]]
+    tj[2, 5] = [lim[0] + 60.0 / 32 * 4, lim[2] + 60.0 / 30 * 7]
+    out["goal_tj"] = tj
+    out["goal_limits"] = np.asarray(lim)
+    for w in (1, 3, 4, 7):
+        out[f"goals_w{w}"] = np.stack([ref_utils.compute_goals_fixed(t, *lim, 32, 30, window=w) for t in tj])
+    out["get_goal"] = np.asarray([ref_utils.get_goal(p, *lim, 32, 30) for p in tj[:, 0]])
+    # basketball collate: 3 scenes of 5 agents
+    To, Tp, n = 4, 6, 5
+    items = [[torch.from_numpy(rng.normal(size=s)).float() for s in ((To, n, 2), (Tp, n, 2), (To, n, 2), (Tp, n, 2), (To, n), (Tp, n))]
+             for _ in range(3)]
+    for i, it in enumerate(items):
+        for j, t in enumerate(it):
+            out[f"bsk_in_{i}_{j}"] = t.numpy()
+    for j, t in enumerate(ref_bsk.seq_collate(items)):
+        out[f"bsk_out_{j}"] = t.numpy()
+    # SDD collate: ragged scenes, per-agent-major items
+    sizes = [2, 5, 3]
+    items = [[torch.from_numpy(rng.normal(size=s)).float()
+              for s in ((m, 2, To), (m, 2, Tp), (m, 2, To), (m, 2, Tp), (m, To), (m, Tp), (m,), (m, To + Tp))] for m in sizes]
+    for i, it in enumerate(items):
+        for j, t in enumerate(it):
+            out[f"sdd_in_{i}_{j}"] = t.numpy()
+    for j, t in enumerate(ref_sdd.seq_collate(items)):
+        out[f"sdd_out_{j}"] = t.numpy()
+    # BasketDataset: the arrays it derives (relative coordinates, obs / pred split) for 4 scenes of 5 agents, read from files
+    import tempfile
+    traj = rng.uniform(0, 45, size=(To + Tp, 4 * n, 2))
+    goals = rng.integers(0, 90, size=(To + Tp, 4 * n)).astype(np.float64)
+    out["ds_traj"], out["ds_goals"] = traj, goals
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "trajectories.npy"), traj)
+        np.save(os.path.join(d, "goals.npy"), goals)
+        ds = ref_bsk.BasketDataset(d, n_agents=n, obs_len=To, pred_len=Tp)
+    for j, t in enumerate(ds[2]):
+        out[f"ds_item2_{j}"] = t.numpy()
+    out["ds_len"] = np.asarray(len(ds))
+    np.savez_compressed(os.path.join(OUT, "data_utils.npz"), **out)
+    print("data_utils.npz:", len(out), "arrays")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         return train_cases()
+    if len(sys.argv) > 1 and sys.argv[1] == "data":
+        return data_case()
+    data_case()
     state_dict_layouts()
     train_cases()
     # --- tiny dims, ragged scenes, every graph x adjacency combination

@@ -1,0 +1,151 @@
+"""CPU: batch layout and goal grid (dagnet_amd.data) against outputs of the reference's own loader code
+(tests/golden/data_utils.npz, written by oracle/make_golden.py data), and the host logic of dagnet_amd.loop
+(KLD warm-up, plateau scheduler, checkpoint dictionary layout)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dagnet_amd import data as D
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "data_utils.npz"))
+
+
+def test_goal_grid_matches_reference():
+    tj, lim = GOLD["goal_tj"], GOLD["goal_limits"]
+    for w in (1, 3, 4, 7):
+        want = GOLD[f"goals_w{w}"]
+        got = np.stack([D.compute_goals_fixed(t, *lim, 32, 30, window=w) for t in tj])
+        assert got.dtype == want.dtype and np.array_equal(got, want)
+        assert np.array_equal(D.compute_goals_fixed(tj, *lim, 32, 30, window=w), want)      # all trajectories at once
+    got = np.asarray([D.get_goal(p, *lim, 32, 30) for p in tj[:, 0]])
+    assert np.array_equal(got, GOLD["get_goal"])
+    assert D.get_goal([lim[1], lim[3]], *lim, 32, 30) == 32 * 30 + 30                       # upper border: index n_cells (reference quirk)
+    with pytest.raises(ValueError):                                                        # below the rectangle: np.max of nothing
+        D.get_goal([lim[0] - 1.0, 5.0], *lim, 32, 30)
+
+
+def _items(prefix, n_items, n_fields):
+    return [[torch.from_numpy(GOLD[f"{prefix}_in_{i}_{j}"]) for j in range(n_fields)] for i in range(n_items)]
+
+
+def test_collate_layouts_match_reference():
+    for prefix, fn, nf in (("bsk", D.seq_collate_bsk, 6), ("sdd", D.seq_collate_sdd, 8)):
+        got = fn(_items(prefix, 3, nf))
+        assert len(got) == nf + 1
+        for j, t in enumerate(got):
+            want = GOLD[f"{prefix}_out_{j}"]
+            assert tuple(t.shape) == want.shape and np.array_equal(t.numpy(), want), (prefix, j)
+        assert got[-1].dtype == torch.int64
+
+
+def test_basket_dataset_and_scene_batcher():
+    traj, goals = GOLD["ds_traj"], GOLD["ds_goals"]
+    ds = D.BasketDataset((traj, goals), n_agents=5, obs_len=4, pred_len=6)
+    assert len(ds) == int(GOLD["ds_len"]) and ds.__max_agents__() == 5
+    for j, t in enumerate(ds[2]):
+        assert np.array_equal(t.numpy(), GOLD[f"ds_item2_{j}"]), j
+    # consecutive scenes: slices equal the collated list; shuffled: the same scenes, rows renumbered
+    want = D.seq_collate_bsk([ds[i] for i in range(len(ds))])
+    (got,) = list(D.SceneBatcher(ds.fields(), ds.scene_ptr, batch_size=8))
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    g = torch.Generator().manual_seed(3)
+    order = torch.randperm(len(ds), generator=torch.Generator().manual_seed(3)).tolist()
+    batches = list(D.SceneBatcher(ds.fields(), ds.scene_ptr, batch_size=3, shuffle=True, generator=g))
+    assert [b[-1].shape[0] for b in batches] == [3, 1]
+    want = D.seq_collate_bsk([ds[i] for i in order[:3]])
+    for a, b in zip(batches[0], want):
+        assert torch.equal(a, b)
+    # data parallel: the ranks' shares of a batch partition its scenes
+    parts = [list(D.SceneBatcher(ds.fields(), ds.scene_ptr, batch_size=4, rank=r, world=2))[0] for r in range(2)]
+    assert torch.equal(torch.cat([p[0] for p in parts], 1), ds.obs_traj)
+
+
+def test_ragged_scene_batcher():
+    ptr = np.array([0, 2, 7, 10, 11])
+    x = torch.arange(11, dtype=torch.float32)[None, :, None].expand(3, 11, 2).contiguous()
+    g = torch.Generator().manual_seed(1)
+    order = torch.randperm(4, generator=torch.Generator().manual_seed(1)).tolist()
+    (b,) = list(D.SceneBatcher([x], ptr, batch_size=4, shuffle=True, generator=g))
+    rows = np.concatenate([np.arange(ptr[s], ptr[s + 1]) for s in order])
+    assert np.array_equal(b[0][0, :, 0].numpy(), rows)
+    sizes = [ptr[s + 1] - ptr[s] for s in order]
+    assert b[-1][:, 1].tolist() == np.cumsum(sizes).tolist() and b[-1][0, 0] == 0
+
+
+def test_kld_warmup_schedule():
+    from dagnet_amd.loop import kld_warmup
+    w = kld_warmup(120, True)
+    ref = np.ones(120)
+    ref[:50] = np.linspace(0, 1, num=50)                 # models/dagnet/train_bsk.py:377-380
+    assert np.array_equal(w, ref)
+    assert np.array_equal(kld_warmup(7, False), np.ones(7))
+
+
+class _Opt:
+    def __init__(self, lr):
+        self.lr = lr
+
+
+def test_plateau_scheduler_follows_torch():
+    from dagnet_amd.loop import PlateauScheduler
+    p = torch.nn.Parameter(torch.zeros(1))
+    topt = torch.optim.Adam([p], lr=1e-3)
+    tsch = torch.optim.lr_scheduler.ReduceLROnPlateau(topt, threshold=1e-2, patience=10, factor=5e-1)
+    mine = PlateauScheduler(_Opt(1e-3))
+    rng = np.random.default_rng(0)
+    metric = 10.0
+    for e in range(200):
+        metric = metric * (0.97 if e < 40 else 1.0) + 0.01 * rng.normal()
+        tsch.step(metric)
+        mine.step(metric)
+        assert mine.optimizer.lr == pytest.approx(topt.param_groups[0]["lr"], rel=0, abs=0), e
+        assert mine.num_bad_epochs == tsch.num_bad_epochs
+    assert mine.optimizer.lr < 1e-3
+    sd = mine.state_dict()
+    assert set(sd) >= {"best", "num_bad_epochs", "last_epoch", "patience", "factor", "threshold"}
+    again = PlateauScheduler(_Opt(1e-3))
+    again.load_state_dict(sd)
+    assert again.best == mine.best and again.optimizer.lr == mine.optimizer.lr
+
+
+def test_checkpoint_dictionary_layout(tmp_path):
+    """Keys and nesting of train_bsk.py:80-93; Adam's state_dict layout inside."""
+    from dagnet_amd import loop
+
+    class FakeAdam:                                    # the attributes of _ops.ClipAdam that the checkpoint code reads
+        def __init__(self, params):
+            self.params, self.lr, self.betas, self.eps, self.step_count = params, 1e-3, (0.9, 0.999), 1e-8, 3
+            self.m = [torch.full_like(p, 0.5) for p in params]
+            self.v = [torch.full_like(p, 0.25) for p in params]
+
+    model = torch.nn.Linear(3, 2)
+    opt = FakeAdam(list(model.parameters()))
+    sch = loop.PlateauScheduler(opt)
+
+    class A:
+        pass
+    args = A()
+    args.g_dim, args.run = 90, "x"
+    fn = tmp_path / "ck.pth"
+    loop.save_checkpoint(fn, args, 7, model, opt, sch, 1.5, [(1.0, 5)], [(2.0, 5)], [(3.0, 5)], [(4.0, 5)])
+    ck = torch.load(fn, weights_only=True)
+    w_saved = model.weight.detach().clone()
+    assert set(ck) == {"args", "epoch", "best_ade", "model_state_dict", "optimizer_state_dict", "lr_scheduler_state_dict",
+                       "ade_list_val", "fde_list_val", "ade_list_test", "fde_list_test"}
+    ref = torch.optim.Adam(model.parameters(), lr=1e-3)
+    model(torch.ones(1, 3)).sum().backward()
+    ref.step()
+    rsd = ref.state_dict()
+    osd = ck["optimizer_state_dict"]
+    assert set(osd) == set(rsd) and set(osd["state"][0]) >= {"step", "exp_avg", "exp_avg_sq"}
+    assert set(osd["param_groups"][0]) >= {"lr", "betas", "eps", "weight_decay", "amsgrad", "params"}
+    ref.load_state_dict(osd)                           # torch's own optimizer accepts it
+    opt2 = FakeAdam(list(model.parameters()))
+    opt2.step_count = 0
+    model2 = torch.nn.Linear(3, 2)
+    got = loop.load_checkpoint(fn, model2, opt2, loop.PlateauScheduler(opt2))
+    assert got["epoch"] == 7 and opt2.step_count == 3 and torch.equal(opt2.m[0], opt.m[0])
+    assert torch.equal(model2.weight, w_saved)

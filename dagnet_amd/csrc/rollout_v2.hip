@@ -125,6 +125,16 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         int lane = lane0, s0 = s00, n = n0;
         asm volatile("" : "+v"(lane), "+v"(s0), "+v"(n));
         const int lh = lane >> 5, lc = lane & 31;
+        // Same idea for what depends on the row and the step: left alone, the compiler turns every [k][t][row] address into
+        // a 64-bit per-lane induction pointer and the first Philox round of every counter into a loop invariant, and then
+        // spills them to scratch (reloaded with a full memory round trip in the middle of the goal draw).  Recomputing
+        // from opaque copies costs a few VALU instructions per step.
+        int tq = t;
+        asm volatile("" : "+s"(tq));
+        uint32_t rrow = rngrow;
+        int krow_t = krow, grow_t = grow;
+        asm volatile("" : "+v"(rrow), "+v"(krow_t), "+v"(grow_t));
+        const int64_t row_t = ((int64_t)krow_t * R.T + tq) * NK + (live ? grow_t : 0);      // row of [K][T][N] arrays, this step
         auto build_mask = [&]() {
             // rows j = FR(r)+4*lh of the tile that are in this row's scene and have adjacency > 0
             __syncthreads();
@@ -160,6 +170,9 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         };
         T16 d[DT];
         auto build_disposition = [&]() {    // flattened xy of the scene's agents, zero padded
+            int s0 = s00, ln = lane0;       // opaque per call: the two calls of a step must not share (and spill) their LDS addresses
+            asm volatile("" : "+v"(s0), "+v"(ln));
+            const int lh = ln >> 5;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -214,7 +227,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             float best = -1.f;
             int bi = 0x7fffffff;
             const int Gm1 = R.G - 1;
-            const int64_t qrow = ((((int64_t)krow * R.T + t) * NK + (live ? grow : 0)) * R.G);
+            const int64_t qrow = row_t * R.G;
 #pragma unroll
             for (int nt = 0; nt < GT; ++nt)
 #pragma unroll
@@ -225,7 +238,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #pragma unroll
                         for (int i = 0; i < 4; ++i) q4[i] = R.q[qrow + min(f0 + i, Gm1)];
                     } else {
-                        const uint4 u = philox4x32(make_uint4(rngrow, (uint32_t)t, (uint32_t)(f0 >> 2), 1u),
+                        const uint4 u = philox4x32(make_uint4(rrow, (uint32_t)tq, (uint32_t)(f0 >> 2), 1u),
                                                       make_uint2((uint32_t)R.seed, (uint32_t)(R.seed >> 32)));
                         const uint32_t u4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
@@ -246,9 +259,9 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
                 const int oi = xhalf(bi);
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
             }
-            if (R.force_goals && live) bi = min(max(R.force_goals[((int64_t)krow * R.T + t) * NK + grow], 0), R.G - 1);
+            if (R.force_goals && live) bi = min(max(R.force_goals[row_t], 0), R.G - 1);
             gi = min(bi, R.G - 1);
-            if (R.out_goals && live && lh == 0) R.out_goals[((int64_t)krow * R.T + t) * NK + grow] = gi;
+            if (R.out_goals && live && lh == 0) R.out_goals[row_t] = gi;
         }
         PH(3);
         if constexpr (HEAD) {
@@ -285,9 +298,9 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
                 if (R.eps) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
-                        e4[i] = live ? R.eps[(((int64_t)krow * R.T + t) * NK + grow) * ZD + f0 + i] : 0.f;
+                        e4[i] = live ? R.eps[row_t * ZD + f0 + i] : 0.f;
                 } else {
-                    const uint4 u = philox4x32(make_uint4(rngrow, (uint32_t)t, (uint32_t)(f0 >> 2), 0u),
+                    const uint4 u = philox4x32(make_uint4(rrow, (uint32_t)tq, (uint32_t)(f0 >> 2), 0u),
                                                   make_uint2((uint32_t)R.seed, (uint32_t)(R.seed >> 32)));
                     e4[0] = (float)(u.x >> 8) * (1.0f / 16777216.0f);
                     e4[1] = (float)(u.y >> 8) * (1.0f / 16777216.0f);
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         dmx += wp.ld1(0, W.dec_mean_b);
         dmy += wp.ld1(0, W.dec_mean_b + 1);
         if (live && lh == 0)
-            *reinterpret_cast<float2 *>(R.out + (((int64_t)krow * R.T + t) * NK + grow) * 2) = make_float2(dmx, dmy);
+            *reinterpret_cast<float2 *>(R.out + row_t * 2) = make_float2(dmx, dmy);
         PH(6);
         // -------------------------------------------------------------------- phi_x of the prediction
 #pragma unroll

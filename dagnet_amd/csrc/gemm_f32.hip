@@ -322,8 +322,8 @@ static hipError_t launch_nt_cfg(const NtArgs &a, bool veca, bool vecb, bool tran
 
 // General entry: C = act([C +] A op(B) + bias + gather), op(B) = W[N,K]^T (transb = 0) or B[K,N] (transb = 1).
 // An operand that is 16-byte aligned with a row stride and a load-direction extent that are multiples of 4 takes float4
-// staging loads, anything else scalar loads.  Tiles: 128x128 for wide outputs, 128x64 / 128x32 (2 workgroups per CU) for
-// the narrow layers, which are bound by streaming A and C rather than by the MFMAs.
+// staging loads, anything else scalar loads.  Tiles: 128x128 for wide outputs, 128x96 / 64x64 / 128x32 for the narrow layers,
+// which are bound by streaming A and C rather than by the MFMAs (small tiles = more workgroups in flight per CU).
 extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
                               int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
                               const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st) {
@@ -332,8 +332,9 @@ extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64
     const bool veca = !((lda & 3) || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15));
     const bool vecb = !((ldb & 3) || ((transb ? N : K) & 3) || (reinterpret_cast<uintptr_t>(B) & 15));
     gemm::NtArgs a{A, lda, B, ldb, bias, C, ldc, M, N, K, slope, gather, gidx, gs_g, gs_n, act, accumulate};
-    if (N > 64) return gemm::launch_nt_cfg<2, 2, 2, 2>(a, veca, vecb, transb != 0, st);     // 128 x 128
-    if (N > 32) return gemm::launch_nt_cfg<2, 2, 2, 1>(a, veca, vecb, transb != 0, st);     // 128 x 64
+    if (N > 96) return gemm::launch_nt_cfg<2, 2, 2, 2>(a, veca, vecb, transb != 0, st);     // 128 x 128
+    if (N > 64) return gemm::launch_nt_cfg<4, 1, 1, 3>(a, veca, vecb, transb != 0, st);     // 128 x 96 (g_dim = 90: no padded column tile)
+    if (N > 32) return gemm::launch_nt_cfg<2, 2, 1, 1>(a, veca, vecb, transb != 0, st);     // 64 x 64 (measured: 7 % of a training step over 128 x 64)
     return gemm::launch_nt_cfg<4, 1, 1, 1>(a, veca, vecb, transb != 0, st);                 // 128 x 32
 }
 
@@ -350,11 +351,11 @@ extern "C" hipError_t dn_gemm_nt(const float *A, int64_t lda, const float *W, in
 
 // C[N,K] (+)= A[M,N]^T B[M,K], deterministic two-pass split over M.  `part` is a workspace of
 // dn_gemm_tn_workspace(M, N, K) floats.
-// splits over the rows: enough workgroups to fill 256 CUs twice, at least 256 rows each
+// splits over the rows: enough workgroups for 256 CUs x 6 (the kernel is bound by load latency, not by its MFMAs), at least 128 rows each
 extern "C" int64_t dn_gemm_tn_splits(int M, int N, int K) {
     const int64_t blocks = (int64_t)((N + 63) / 64) * ((K + 63) / 64);
-    int64_t s = (768 + blocks - 1) / blocks;
-    const int64_t cap = (M + 255) / 256;
+    int64_t s = (1536 + blocks - 1) / blocks;
+    const int64_t cap = (M + 127) / 128;
     if (s > cap) s = cap;
     return s < 1 ? 1 : (s > 512 ? 512 : s);
 }

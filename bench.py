@@ -216,7 +216,7 @@ def bench_train(opt, wl, rank, world, dev, dist):
                    "rows_per_gpu": n_rows, "parallelism": f"scenes sharded x{world}, one all-reduce of 184 350 fp32 gradients per step"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
-                     "kernel": "layer-by-layer operators (gemm_nt_kernel + train_ops.hip), launch-bound at this batch"},
+                     "kernel": "layer-by-layer operators (gemm_f32.hip + train_ops.hip): bound by streaming activations, see DESIGN.md 4.5"},
         "loss": float(loss.detach()),
     }
     if not opt.no_cpu_baseline and world == 1:

@@ -332,8 +332,10 @@ extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64
     const bool veca = !((lda & 3) || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15));
     const bool vecb = !((ldb & 3) || ((transb ? N : K) & 3) || (reinterpret_cast<uintptr_t>(B) & 15));
     gemm::NtArgs a{A, lda, B, ldb, bias, C, ldc, M, N, K, slope, gather, gidx, gs_g, gs_n, act, accumulate};
+    if (N > 128 && N <= 192) return gemm::launch_nt_cfg<2, 2, 1, 3>(a, veca, vecb, transb != 0, st);   // 64 x 192: the GRU gate columns in one tile, A read once
     if (N > 96) return gemm::launch_nt_cfg<2, 2, 2, 2>(a, veca, vecb, transb != 0, st);     // 128 x 128
-    if (N > 64) return gemm::launch_nt_cfg<4, 1, 1, 3>(a, veca, vecb, transb != 0, st);     // 128 x 96 (g_dim = 90: no padded column tile)
+    // 128 x 96: g_dim = 90 in one column tile
+    if (N > 64) return gemm::launch_nt_cfg<4, 1, 1, 3>(a, veca, vecb, transb != 0, st);
     if (N > 32) return gemm::launch_nt_cfg<2, 2, 1, 1>(a, veca, vecb, transb != 0, st);     // 64 x 64 (measured: 7 % of a training step over 128 x 64)
     return gemm::launch_nt_cfg<4, 1, 1, 1>(a, veca, vecb, transb != 0, st);                 // 128 x 32
 }

@@ -349,3 +349,39 @@ def test_wide_forward_agrees_with_generic_kernel(compact):
     for f, s, what in zip(fast[:3], slow[:3], ("KLD", "NLL", "CE")):
         assert abs(float(f) - float(s)) <= 2e-5 * max(1.0, abs(float(s))), (what, float(f), float(s))
     assert float((fast[3] - slow[3]).abs().max()) < 5e-5
+
+
+@pytest.mark.parametrize("g_dim,cells", [(12, (3, 4)), (40, (5, 8)), (64, (8, 8)), (96, (12, 8))])
+def test_register_resident_kernel_with_any_goal_width(g_dim, cells):
+    """g_dim below 65 leaves whole goal tiles empty: every goal-wide segment (chain blocks, bias, BatchNorm table, one-hot
+    tables) is padded to three tiles so that the kernel's compile-time layout holds (params_v2.h v2_layout).  sample and
+    the teacher-forced pass against the oracle, goals forced so that rows stay comparable."""
+    a, m, sd = _model("dagnet", n_max=6, n_layers=2, g_dim=g_dim)
+    sizes, T, seed = [3, 6, 2, 5], 6, 31 + g_dim
+    batch = syn.make_batch(sizes, 5, T, seed, kind="sdd", g_cells=cells)
+    obs, gt, obs_rel, gt_rel, og, pg, sse = batch
+    N = obs.shape[1]
+    assert m.hip_plan(DEV, scene_ptr_from_sse(sse), 1).info()["sample_kernel"].startswith("rollout_v2")
+    h = syn.uniform_noise(seed, "h0", (2, N, 64)) - 0.5
+    eps, q = syn.uniform_noise(seed, "eps", (1, T, N, a.z_dim)), syn.exp1_noise(seed, "q", (1, T, N, g_dim))
+    cfg = orc.make_cfg(n_max_agents=6, n_layers=2, g_dim=g_dim)
+    tr = []
+    with torch.no_grad():
+        want = orc.dagnet_sample(sd, cfg, T, h, obs[-1], orc.one_hot(og[-1], g_dim), sse, eps[0], q[0], trace=tr)
+    wg = torch.stack([t["goal"] for t in tr])[None].to(torch.int32)
+    d = [t.to(DEV) for t in batch]
+    got = m.sample_k(1, T, h.to(DEV), d[0][-1], d[4][-1].to(torch.int32), sse, eps=eps.to(DEV), q=q.to(DEV), force_goals=wg.to(DEV))
+    err = (got[0].cpu() - want).abs() - (DISP_ATOL + DISP_RTOL * want.abs())
+    assert err.max().item() <= 0, f"max abs diff {(got[0].cpu() - want).abs().max().item():.3e}"
+    free, goals = m.sample_k(1, T, h.to(DEV), d[0][-1], d[4][-1].to(torch.int32), sse, eps=eps.to(DEV), q=q.to(DEV), return_goals=True)
+    safe = torch.stack([t["margin"] for t in tr])[0] > 1e-4
+    assert torch.equal(goals.cpu()[0, 0][safe], wg[0, 0][safe]) and int(goals.max()) < g_dim
+    # teacher-forced pass over the observed steps
+    adj = orc.adjacency_seq(cfg, sse, torch.cat((obs, gt), 0))
+    eps_f = syn.uniform_noise(seed, "eps_f", (4, N, a.z_dim))
+    with torch.no_grad():
+        wk, wn, wc, wh = orc.dagnet_forward(sd, cfg, obs, obs_rel, orc.one_hot(og, g_dim), sse, adj, eps_f)
+    k, n, c, hh = m(d[0], d[2], d[4].to(torch.int32), sse, adj.to(DEV), eps=eps_f.to(DEV))
+    for gotv, wantv in ((k, wk), (n, wn), (c, wc)):
+        assert float(gotv) == pytest.approx(float(wantv), rel=1e-4, abs=1e-5)
+    assert (hh.cpu() - wh).abs().max() < 2e-4

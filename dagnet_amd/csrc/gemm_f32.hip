@@ -12,6 +12,7 @@
 // Row stride of the LDS tiles is 36 floats: 16 consecutive rows x 16 B then cover all 64 banks exactly once.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 
 namespace gemm {
 
@@ -63,12 +64,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
     // XCD a contiguous range of logical tiles, column blocks fastest, so that the nbn workgroups that read the same A
     // rows run back to back on ONE XCD (measured before: 4x the algorithmic HBM reads on the 1920 -> 960 layer, every
     // XCD fetching every A row block).  W is small enough to stay resident in every L2.
+    // Every workgroup walks a strided list of tiles of its XCD's range and prefetches the first chunk of the next tile while
+    // it computes the last chunk of the current one (one tile per workgroup: all workgroups of a CU load, then all compute).
     const int nbn = (p.N + BN - 1) / BN;
     const int64_t total = (int64_t)((p.M + BM - 1) / BM) * nbn, per_xcd = (total + 7) / 8;
-    const int64_t tile = (int64_t)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (tile >= total) return;
-    const int bm = (int)(tile / nbn), bn = (int)(tile % nbn);
-    const int m0 = bm * BM, n0 = bn * BN;
+    const int64_t xbeg = (int64_t)(blockIdx.x & 7) * per_xcd, xend = min(xbeg + per_xcd, total);
+    const int64_t tstride = gridDim.x >> 3;
+    int64_t tile = xbeg + (blockIdx.x >> 3);
+    if (tile >= xend) return;
+    int m0 = (int)(tile / nbn) * BM, n0 = (int)(tile % nbn) * BN;
 
     const int lrow = tid >> 3, lc4 = (tid & 7) * 4;          // this thread's (row, k) inside a 32-row slab of a chunk
     f32x4 ga[LA], gb[LB];
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
         return v;
     };
     constexpr int BN4 = BN / 4;
-    auto gload = [&](int k0) {
+    auto gload = [&](int m0, int n0, int k0) {
 #pragma unroll
         for (int i = 0; i < LA; ++i) ga[i] = ld4(p.A, p.lda, m0 + lrow + 32 * i, p.M, k0 + lc4, p.K, VECA);
 #pragma unroll
@@ -125,53 +129,66 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    gload(0);
+    gload(m0, n0, 0);
     sstore(0);
     __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) gload((kc + 1) * BK);
-        const float *a_base = sA + (buf * BM + (wm * TM) * 32 + lr) * LDT + 4 * lh;
-        const float *b_base = sB + (buf * BN + (wn * TN) * 32 + lr) * LDT + 4 * lh;
+    int buf = 0;
+    while (true) {
+        const int64_t ntile = tile + tstride;
+        const bool more = ntile < xend;
+        const int nm0 = more ? (int)(ntile / nbn) * BM : 0, nn0 = more ? (int)(ntile % nbn) * BN : 0;
+        for (int kc = 0; kc < nk; ++kc) {
+            const bool last = kc + 1 == nk, pf = !last || more;          // uniform over the workgroup
+            if (!last) gload(m0, n0, (kc + 1) * BK);
+            else if (more) gload(nm0, nn0, 0);
+            const float *a_base = sA + (buf * BM + (wm * TM) * 32 + lr) * LDT + 4 * lh;
+            const float *b_base = sB + (buf * BN + (wn * TN) * 32 + lr) * LDT + 4 * lh;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 fa[TM], fb[TN];
+            for (int j = 0; j < 4; ++j) {
+                f32x4 fa[TM], fb[TN];
 #pragma unroll
-            for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const f32x4 *>(a_base + a * 32 * LDT + 8 * j);
+                for (int a = 0; a < TM; ++a) fa[a] = *reinterpret_cast<const f32x4 *>(a_base + a * 32 * LDT + 8 * j);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const f32x4 *>(b_base + b * 32 * LDT + 8 * j);
+                for (int b = 0; b < TN; ++b) fb[b] = *reinterpret_cast<const f32x4 *>(b_base + b * 32 * LDT + 8 * j);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int a = 0; a < TM; ++a)
+                    for (int a = 0; a < TM; ++a)
 #pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][i], fb[b][i], acc[a][b], 0, 0, 0);
+                        for (int b = 0; b < TN; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][i], fb[b][i], acc[a][b], 0, 0, 0);
+            }
+            if (pf) sstore(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
         }
-        if (kc + 1 < nk) sstore(buf ^ 1);
-        __syncthreads();
-    }
 
-    // epilogue: lane = output column, register r <-> row (r&3) + 8(r>>2) + 4h of the 32x32 tile
+        // epilogue: lane = output column, register r <-> row (r&3) + 8(r>>2) + 4h of the 32x32 tile
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-        const int col = n0 + (wn * TN + b) * 32 + lr;
-        const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+        for (int b = 0; b < TN; ++b) {
+            const int col = n0 + (wn * TN + b) * 32 + lr;
+            const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int a = 0; a < TM; ++a) {
-            const int rbase = m0 + (wm * TM + a) * 32 + 4 * lh;
+            for (int a = 0; a < TM; ++a) {
+                const int rbase = m0 + (wm * TM + a) * 32 + 4 * lh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + (r & 3) + 8 * (r >> 2);
-                if (row < p.M && col < p.N) {
-                    float v = acc[a][b][r] + bv;
-                    if (p.gather) v += p.gather[(int64_t)p.gidx[row] * p.gs_g + (int64_t)col * p.gs_n];
-                    float *dst = p.C + (int64_t)row * p.ldc + col;
-                    if (p.accumulate) v += *dst;
-                    *dst = act_apply(p.act, v, p.slope);
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M && col < p.N) {
+                        float v = acc[a][b][r] + bv;
+                        if (p.gather) v += p.gather[(int64_t)p.gidx[row] * p.gs_g + (int64_t)col * p.gs_n];
+                        float *dst = p.C + (int64_t)row * p.ldc + col;
+                        if (p.accumulate) v += *dst;
+                        *dst = act_apply(p.act, v, p.slope);
+                    }
+                    acc[a][b][r] = 0.f;
                 }
             }
         }
+        if (!more) break;
+        tile = ntile;
+        m0 = nm0;
+        n0 = nn0;
     }
 }
 
@@ -304,7 +321,11 @@ static hipError_t launch_nt_cfg(const NtArgs &a, bool veca, bool vecb, bool tran
     const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
     const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     if (tiles <= 0) return hipSuccess;
-    const int64_t blocks = (tiles + 7) / 8 * 8;          // 8 XCDs x equal ranges (the kernel drops the padding)
+    // 8 XCDs x equal ranges of tiles (the kernel drops the padding); at most as many workgroups as are resident at once
+    // (LDS-limited, <= 4 per CU), each walking several tiles.  Fewer, longer-lived workgroups are slower (measured 3 / 2 / 1
+    // per CU: 233 / 245 / 284 ms per training step against 232): bytes in flight come from resident workgroups.
+    const int64_t resident = 256 * std::min<int64_t>(4, (160 * 1024) / (int64_t)lds);
+    const int64_t blocks = std::min((tiles + 7) / 8 * 8, resident);
     if (blocks > 0x7fffffffLL) return hipErrorInvalidValue;
     const dim3 g((unsigned)blocks), t(256);
 #define DN_NT_CASE(VA, VB, TB)                                                                                        \

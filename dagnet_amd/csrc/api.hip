@@ -90,9 +90,9 @@ struct dagnet_model {
     size_t wp_floats = 0;
     int device = 0;
     bool v2 = false;            // the register-resident kernel (rollout_v2.hip) covers this model
-    V2Weights w2;               // absolute offsets into d_wp (forward_v2.hip reads this table)
+    V2Weights w2;               // absolute offsets into d_wp (read by model 3 only: wide goal head)
     V2Weights *d_w2 = nullptr;  // device copy of w2
-    int v2_base = 0;            // start of the v2 region in d_wp: rollout_v2.hip uses compile-time offsets relative to it
+    int v2_base = 0;            // start of the v2 region in d_wp: the v2 kernels use compile-time offsets relative to it
     // wide goal head (wide_head.hip) + register-resident kernel model 3 for the rest of the step
     bool wide = false;
     WideWeights ww;
@@ -1281,7 +1281,7 @@ extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32
         // register-resident teacher-forced pass (forward_v2.hip); GAT consumes only the adjacency's support
         V2Run r;
         memset(&r, 0, sizeof(r));
-        r.wp = m->d_wp;
+        r.wp = m->d_wp + m->v2_base;      // compile-time offsets relative to the v2 region
         r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
         r.S = p->S; r.N = p->N; r.K = 1; r.T = T; r.n_tiles = p->n_tiles2;
         r.G = m->dims.G; r.D = m->dims.D; r.adj_type = m->dims.adj_type; r.alpha = m->dims.alpha; r.sigma = m->dims.sigma;

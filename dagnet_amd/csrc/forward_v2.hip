@@ -17,7 +17,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 template <int MODEL, int NL, int ZD, int GM>
 __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
-    const V2Weights &W = *Wp;
+    // compile-time segment offsets relative to the v2 region, as in rollout_v2.hip (model 3 reads the packer's table)
+    static constexpr V2Layout LO = v2_layout(MODEL, NL, ZD, GM);
+    const V2Weights &W = MODEL == 3 ? *Wp : LO.off;
     __shared__ float xch[32 * 4 + 64];
     __shared__ float stash[(MODEL == 2 || MODEL == 4) ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
     float *pos = xch + 128;
@@ -27,7 +29,7 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
     // MODEL 3: DAG-Net whose goal head (and its CE term) runs outside (wide_head.hip); steps [t_begin, t_end) per launch,
     // hidden state read from / written back to h_out, loss partials accumulated over the launches
     constexpr bool DAG = MODEL >= 2, HEAD = MODEL == 2 || MODEL == 4, EXT = MODEL == 3, GRAPH = MODEL != 0;
-    constexpr int GT = 3;
+    constexpr int GT = V2_GT;
     constexpr int DT = (EXT || MODEL == 4) ? 2 : 1;
     constexpr int MLT = ZD == 32 ? 2 : 1;
 

@@ -145,8 +145,8 @@ constexpr V2Layout v2_layout(int model, int nl, int zd, int gm) {
 }
 
 struct V2Run {
-    const float *wp;                 // chain-packed weights: start of the buffer (forward_v2: absolute offsets from the table)
-                                     // or of its v2 region (rollout_v2: compile-time relative offsets, v2_layout())
+    const float *wp;                 // chain-packed weights: start of the v2 region (compile-time relative offsets, v2_layout())
+                                     // or, for model 3, of the whole buffer (absolute offsets from the packer's table)
     const int32_t *scene_ptr, *tile_u0, *tile_nu;
     int32_t S, N, K, T, n_tiles;
     int32_t G, D, adj_type;

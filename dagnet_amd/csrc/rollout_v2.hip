@@ -39,6 +39,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     // also (NL == 2): the top layer's state is parked while GRU layer 0 runs (its 4 input tiles + 2 state tiles + gate
     // temporaries do not fit beside it; the compiler would spill ~140 registers to scratch memory instead)
     __shared__ float stash[(MODEL == 2 || MODEL == 4) ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
+    __shared__ float gbias[NL * GRU_BIAS_FLOATS];      // GRU gate biases (v2_common.h gru_bias_to_lds)
     float *pos = xch + 128;                 // [32][2] current absolute positions of the tile rows
     const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
 #ifdef DN_V2_STAGGER
@@ -93,6 +94,8 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     if (DAG && live) gi = min(max(R.g0[srow], 0), R.G - 1);
     unsigned amask = 0;
 
+#pragma unroll
+    for (int l = 0; l < NL; ++l) gru_bias_to_lds(gbias + l * GRU_BIAS_FLOATS, wp, W.gru[l], lane);
     const int first_off = HEAD ? W.dec_goal0.w[0] : W.prior0.w[0];
     WBlk pre = wload(wp, first_off, lane);
 #ifdef DN_PROFILE
@@ -404,13 +407,13 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stash[(nt * 16 + r) * 64 + lane] = h[1][nt][r];
         }
-        pre = gru<4>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? W.gru[1].nh.w[0] : after_gru);
+        pre = gru<4, true>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? W.gru[1].nh.w[0] : after_gru, gbias);
         if constexpr (NL == 2) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[1][nt][r] = stash[(nt * 16 + r) * 64 + lane];
-            pre = gru<2>(h[0], h[1], wp, W.gru[1], lane, pre, after_gru);
+            pre = gru<2, true>(h[0], h[1], wp, W.gru[1], lane, pre, after_gru, gbias + GRU_BIAS_FLOATS);
         }
         PH(8);
         // -------------------------------------------------------------------- graph refinement of h[-1]

@@ -338,11 +338,27 @@ __device__ __forceinline__ WBlk gcn(const T16 (&x)[KT], T16 (&out)[NT], const WB
     return pre;
 }
 
+// Gate biases of one GRU layer for the register-resident kernels: [nh | r | ni | z][64] floats.  The rollout kernel keeps
+// them in LDS (copied once per wave by gru_bias_to_lds): a gate's bias is needed right after its last MFMA, where a load
+// from L2 is a fully exposed round trip (16 of them per step with two layers), an LDS read a tenth of that.
+constexpr int GRU_BIAS_FLOATS = 4 * 64;
+__device__ __forceinline__ void gru_bias_to_lds(float *dst, const WBuf &wp, const V2Gru &Gw, int lane) {
+    dst[0 * 64 + lane] = wp.ld1(lane * 4, Gw.nh.bias);
+    dst[1 * 64 + lane] = wp.ld1(lane * 4, Gw.r.bias);
+    dst[2 * 64 + lane] = wp.ld1(lane * 4, Gw.ni.bias);
+    dst[3 * 64 + lane] = wp.ld1(lane * 4, Gw.z.bias);
+}
+
 // One GRU layer.  xin: KX input tiles; h: 2 tiles (R = 64), updated in place.
-template <int KX>
+// LB: the layer's biases are in LDS at lb (gru_bias_to_lds); else they are loaded from the weight buffer.
+template <int KX, bool LB = false>
 __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBuf &wp, const V2Gru &Gw, int lane, WBlk pre,
-                                    int next_off) {
+                                    int next_off, const float *lb = nullptr) {
     const int lh = lane >> 5;
+    auto bias4 = [&](int gate, int goff, int f) -> float4 {      // 4 consecutive features f + 4*lh .. of gate `gate`
+        if constexpr (LB) return *reinterpret_cast<const float4 *>(lb + gate * 64 + f + 4 * lh);
+        else return wp.ld4(lh * 16, goff + f);
+    };
     T16 hn[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -355,7 +371,7 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
         pre = mm<1, 2, false>(acc, wp, Gw.nh.w[0] + oh, h, lane, pre, Gw.r.w[0] + ox);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const float4 b = wp.ld4(lh * 16, Gw.nh.bias + nt * 32 + 8 * a);
+            const float4 b = bias4(0, Gw.nh.bias, nt * 32 + 8 * a);
             tt[4 * a + 0] = acc[0][4 * a + 0] + b.x; tt[4 * a + 1] = acc[0][4 * a + 1] + b.y;
             tt[4 * a + 2] = acc[0][4 * a + 2] + b.z; tt[4 * a + 3] = acc[0][4 * a + 3] + b.w;
         }
@@ -364,7 +380,7 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
         pre = mm<1, 2, false>(acc, wp, Gw.r.w[1] + oh, h, lane, pre, Gw.ni.w[0] + ox);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const float4 b = wp.ld4(lh * 16, Gw.r.bias + nt * 32 + 8 * a);
+            const float4 b = bias4(1, Gw.r.bias, nt * 32 + 8 * a);
             tt[4 * a + 0] *= sigm(acc[0][4 * a + 0] + b.x); tt[4 * a + 1] *= sigm(acc[0][4 * a + 1] + b.y);
             tt[4 * a + 2] *= sigm(acc[0][4 * a + 2] + b.z); tt[4 * a + 3] *= sigm(acc[0][4 * a + 3] + b.w);
         }
@@ -372,7 +388,7 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
         pre = mm<1, KX, false>(acc, wp, Gw.ni.w[0] + ox, xin, lane, pre, Gw.z.w[0] + ox);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const float4 b = wp.ld4(lh * 16, Gw.ni.bias + nt * 32 + 8 * a);
+            const float4 b = bias4(2, Gw.ni.bias, nt * 32 + 8 * a);
             ng[4 * a + 0] = ftanh((acc[0][4 * a + 0] + b.x) + tt[4 * a + 0]); ng[4 * a + 1] = ftanh((acc[0][4 * a + 1] + b.y) + tt[4 * a + 1]);
             ng[4 * a + 2] = ftanh((acc[0][4 * a + 2] + b.z) + tt[4 * a + 2]); ng[4 * a + 3] = ftanh((acc[0][4 * a + 3] + b.w) + tt[4 * a + 3]);
         }
@@ -381,7 +397,7 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
         pre = mm<1, 2, false>(acc, wp, Gw.z.w[1] + oh, h, lane, pre, nt == 0 ? Gw.nh.w[0] + 2 * 1024 : next_off);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
-            const float4 b = wp.ld4(lh * 16, Gw.z.bias + nt * 32 + 8 * a);
+            const float4 b = bias4(3, Gw.z.bias, nt * 32 + 8 * a);
             const float b4[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) {

@@ -198,32 +198,32 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             PH(0);
             // ---------------------------------------------------------------- goal head
             T16 tg[2];
-            zero(tg);
+            start<2>(tg, wp, W.dec_goal0, gi, lh);
             pre = mm<2, DT, false>(tg, wp, W.dec_goal0.w[0], d, lane, pre, W.dec_goal0.w[1]);
             pre = mm<2, 2, false>(tg, wp, W.dec_goal0.w[1], h[NL - 1], lane, pre, W.dec_goal2.w[0]);
-            finish<2, 2>(tg, wp, W.dec_goal0, gi, lh);
+            activate<2, 2>(tg);
             // the top-layer hidden state is not read again until the prior: park it as well
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stash[(nt * 16 + r) * 64 + lane] = h[NL - 1][nt][r];
             T16 decg[GT];
-            zero(decg);
+            start<GT>(decg, wp, W.dec_goal2, 0, lh);
             pre = mm<GT, 2, false>(decg, wp, W.dec_goal2.w[0], tg, lane, pre, W.lg_goals.w[0]);
-            finish<0, GT>(decg, wp, W.dec_goal2, 0, lh);
+            activate<0, GT>(decg);
             softmax_feat<GT>(decg, R.G, lh);
             PH(1);
             // lg_goals = W1.dec_g + W2.g_graph: the dec_g half runs before the graph so that dec_g is dead
             // once the graph has consumed it (peak registers: gc + gg instead of dec_g + gg + gc)
             T16 gc[GT];
-            zero(gc);
+            start<GT>(gc, wp, W.lg_goals, 0, lh);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.g_goal.heads);
             T16 gg[GT];
             if constexpr (GM == 2) pre = gcn<GT, GT>(decg, gg, wp, W.g_goal, adjval, lane, pre, W.lg_goals.w[1]);
             else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1]);
             PH(2);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.prior0.w[0]);
-            finish<0, GT>(gc, wp, W.lg_goals, 0, lh);
+            activate<0, GT>(gc);
             softmax_feat<GT>(gc, R.G, lh);
             // categorical draw: argmax_g exp(p_g) / q_g, q ~ Exp(1).  Branch-free (selects only): features are visited in
             // increasing order within a lane, so a strict '>' keeps the first maximum; out-of-range features score -1.
@@ -276,18 +276,18 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         // -------------------------------------------------------------------- prior
         T16 ta[2], tb[2];
         DBG(7, h[NL - 1], 2);
-        zero(ta);
+        start<2>(ta, wp, W.prior0, gi, lh);
         pre = mm<2, 2, false>(ta, wp, W.prior0.w[0], h[NL - 1], lane, pre, W.prior2.w[0]);
-        finish<1, 2>(ta, wp, W.prior0, gi, lh);
+        activate<1, 2>(ta);
         DBG(0, ta, 2);
-        zero(tb);
+        start<2>(tb, wp, W.prior2, 0, lh);
         pre = mm<2, 2, false>(tb, wp, W.prior2.w[0], ta, lane, pre, W.prior_ml.w[0]);
-        finish<1, 2>(tb, wp, W.prior2, 0, lh);
+        activate<1, 2>(tb);
         constexpr int MLT = ZD == 32 ? 2 : 1;      // [mean ; logvar] = 2*z_dim features
         T16 ml[MLT];
-        zero(ml);
+        start<MLT>(ml, wp, W.prior_ml, 0, lh);
         pre = mm<MLT, 2, false>(ml, wp, W.prior_ml.w[0], tb, lane, pre, W.phi_z0.w[0]);
-        finish<0, MLT>(ml, wp, W.prior_ml, 0, lh);
+        activate<0, MLT>(ml);
         DBG(1, tb, 2);
         DBG(2, ml, MLT);
         PH(4);
@@ -326,15 +326,15 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         DBG(3, z, 1);
         PH(5);
         // -------------------------------------------------------------------- phi_z, decoder
-        zero(ta);
+        start<2>(ta, wp, W.phi_z0, 0, lh);
         pre = mm<2, 1, false>(ta, wp, W.phi_z0.w[0], z, lane, pre, W.phi_z2.w[0]);
-        finish<1, 2>(ta, wp, W.phi_z0, 0, lh);
+        activate<1, 2>(ta);
         T16 pz[2];
-        zero(pz);
+        start<2>(pz, wp, W.phi_z2, 0, lh);
         pre = mm<2, 2, false>(pz, wp, W.phi_z2.w[0], ta, lane, pre, W.dec0.w[0]);
-        finish<1, 2>(pz, wp, W.phi_z2, 0, lh);
+        activate<1, 2>(pz);
         DBG(4, pz, 2);
-        zero(ta);
+        start<2>(ta, wp, W.dec0, gi, lh);
         if (DAG) {
             // rebuilt from the positions in LDS (unchanged since the start of the step) rather than kept live
             build_disposition();
@@ -345,10 +345,10 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             pre = mm<2, 2, false>(ta, wp, W.dec0.w[0], pz, lane, pre, W.dec0.w[1]);
             pre = mm<2, 2, false>(ta, wp, W.dec0.w[1], h[NL - 1], lane, pre, W.dec2.w[0]);
         }
-        finish<1, 2>(ta, wp, W.dec0, gi, lh);
-        zero(tb);
+        activate<1, 2>(ta);
+        start<2>(tb, wp, W.dec2, 0, lh);
         pre = mm<2, 2, false>(tb, wp, W.dec2.w[0], ta, lane, pre, W.phi_x2.w[0]);
-        finish<1, 2>(tb, wp, W.dec2, 0, lh);
+        activate<1, 2>(tb);
         DBG(5, ta, 2);
         DBG(6, tb, 2);
         // dec_mean: 2 outputs over 64 features, each half sums its 32 features then the halves combine
@@ -387,9 +387,9 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         T16 xin[4];
         {
             T16 px[2];
-            zero(px);
+            start<2>(px, wp, W.phi_x2, 0, lh);
             pre = mm<2, 2, false>(px, wp, W.phi_x2.w[0], ta, lane, pre, W.gru[0].nh.w[0]);
-            finish<1, 2>(px, wp, W.phi_x2, 0, lh);
+            activate<1, 2>(px);
             xin[0] = px[0]; xin[1] = px[1]; xin[2] = pz[0]; xin[3] = pz[1];
         }
         PH(7);
@@ -426,10 +426,10 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             T16 hg[2];
             if constexpr (GM == 2) pre = gcn<2, 2>(h[NL - 1], hg, wp, W.g_hid, adjval, lane, pre, W.blend.w[0]);
             else pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, lane, pre, W.blend.w[0]);
-            zero(ta);
+            start<2>(ta, wp, W.blend, 0, lh);
             pre = mm<2, 2, false>(ta, wp, W.blend.w[0], hg, lane, pre, W.blend.w[1]);
             pre = mm<2, 2, false>(ta, wp, W.blend.w[1], h[NL - 1], lane, pre, first_off);
-            finish<0, 2>(ta, wp, W.blend, 0, lh);
+            activate<0, 2>(ta);
             h[NL - 1][0] = ta[0];
             h[NL - 1][1] = ta[1];
         }

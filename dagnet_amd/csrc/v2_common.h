@@ -155,6 +155,25 @@ __device__ __forceinline__ void activate(T16 (&x)[NT]) {
             for (int r = 0; r < 16; ++r) x[nt][r] = ACT == 1 ? lrelu(x[nt][r], 0.01f) : fmaxf(x[nt][r], 0.f);
     }
 }
+// The same vector as the INITIAL value of the layer's accumulators instead of an addition after its MFMAs: the loads are
+// issued before the layer's first MFMA block (the scheduler lifts them up to the end of the previous layer's MFMAs, so the
+// round trip to L2 overlaps that layer's activation), and the NT*16 additions per lane disappear.
+template <int NT>
+__device__ __forceinline__ void start(T16 (&x)[NT], const WBuf &wp, const V2Lin &L, int gsel, int lh) {
+    const bool g = L.gather >= 0;
+    const int off = g ? L.gather : L.bias, voff = (g ? gsel * (NT * 32 * 4) : 0) + lh * 16;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 b = wp.ld4(voff, off + nt * 32 + 8 * a);
+            x[nt][4 * a + 0] = b.x;
+            x[nt][4 * a + 1] = b.y;
+            x[nt][4 * a + 2] = b.z;
+            x[nt][4 * a + 3] = b.w;
+        }
+}
+
 // Bias of a dense layer, or - for a layer with a one-hot input - row gsel of its table (api.hip v2_linear: the
 // bias is folded into every row of the table), so either way ONE set of NT*4 independent loads per layer.
 template <int ACT, int NT>

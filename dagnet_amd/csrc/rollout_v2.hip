@@ -363,8 +363,8 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
                 dmx += w0.x * tb[nt][4 * a] + w0.y * tb[nt][4 * a + 1] + w0.z * tb[nt][4 * a + 2] + w0.w * tb[nt][4 * a + 3];
                 dmy += w1.x * tb[nt][4 * a] + w1.y * tb[nt][4 * a + 1] + w1.z * tb[nt][4 * a + 2] + w1.w * tb[nt][4 * a + 3];
             }
-        dmx += xhalf(dmx);
-        dmy += xhalf(dmy);
+        dmx = hsum(dmx);
+        dmy = hsum(dmy);
         dmx += wp.ld1(0, W.dec_mean_b);
         dmy += wp.ld1(0, W.dec_mean_b + 1);
         if (live && lh == 0)

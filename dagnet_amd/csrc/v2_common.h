@@ -61,6 +61,18 @@ __device__ __forceinline__ float lrelu(float v, float s) { return __builtin_amdg
 __device__ __forceinline__ float sigm(float v) { return frcp(1.0f + fexp(-v)); }
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 __device__ __forceinline__ int xhalf(int v) { return __shfl_xor(v, 32); }
+// max / sum over the two lane halves, the result in both: one v_permlane32_swap (gfx950, a VALU instruction) instead of a
+// ds_bpermute round trip through LDS in the middle of a dependent chain (softmax: max, then sum)
+__device__ __forceinline__ float hmax(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);      // r[0] = lower half's v, r[1] = upper half's, in every lane
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float hsum(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <int N>
 __device__ __forceinline__ void zero(T16 (&x)[N]) {
@@ -192,7 +204,7 @@ __device__ __forceinline__ void softmax_feat(T16 (&x)[NT], int G, int lh) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             if (nt * 32 + FR(r) + 4 * lh < G) mx = fmaxf(mx, x[nt][r]);
-    mx = fmaxf(mx, xhalf(mx));
+    mx = hmax(mx);
     float sum = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -202,7 +214,7 @@ __device__ __forceinline__ void softmax_feat(T16 (&x)[NT], int G, int lh) {
             x[nt][r] = e;
             sum += e;
         }
-    sum += xhalf(sum);
+    sum = hsum(sum);
     const float inv = frcp(sum);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -220,14 +232,14 @@ __device__ __forceinline__ void attn_weights(T16 &alpha, float s1, const float (
         e[r] = ((amask >> r) & 1u) ? lrelu(s1 + s2[r], slope) : -9e15f;
         mx = fmaxf(mx, e[r]);
     }
-    mx = fmaxf(mx, xhalf(mx));
+    mx = hmax(mx);
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         e[r] = fexp(e[r] - mx);
         sum += e[r];
     }
-    sum += xhalf(sum);
+    sum = hsum(sum);
     const float inv = frcp(sum);
 #pragma unroll
     for (int r = 0; r < 16; ++r) alpha[r] = e[r] * inv;

@@ -446,6 +446,7 @@ V2Lin v2_pair(Packer &pk, const std::string &a, const std::string &b, int Z, int
 }
 
 // pad: nin and nout are padded to this many features (the goal graph: V2_GT tiles whatever g_dim is)
+static const double kLog2e = 1.4426950408889634074;
 V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, int P, int pad = 0) {
     V2Gat g;
     memset(&g, 0, sizeof(g));
@@ -471,7 +472,7 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
             double acc = 0.0;
             if (k >= nin) return 0.f;
             for (int f = 0; f < F; ++f) acc += (double)Wh[p][(size_t)k * F + f] * (double)ah[p][half * F + f];
-            return (float)acc;
+            return (float)(acc * kLog2e);       // logits in the log2 domain: the kernels' softmax is exp2(e - max)
         },
         2 * P, ninp);
     g.out = pk.chain([=](int n, int k) { return n < nout ? wo[(size_t)k * nout + n] : 0.f; }, noutp, P * F);
@@ -479,7 +480,7 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
         [=](int q, int k) {
             double acc = 0.0;
             for (int n = 0; n < nout; ++n) acc += (double)wo[(size_t)k * nout + n] * (double)aop[q * nout + n];
-            return (float)acc;
+            return (float)(acc * kLog2e);
         },
         2, P * F);
     const Tensor *ga = pk.get(prefix + ".bn1.weight", {nout}), *be = pk.get(prefix + ".bn1.bias", {nout});

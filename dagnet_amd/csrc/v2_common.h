@@ -223,20 +223,27 @@ __device__ __forceinline__ void softmax_feat(T16 (&x)[NT], int G, int lh) {
 }
 
 // attention weights of this lane's row over the 16 tile rows its half owns:
-// alpha[r] = softmax_j( mask ? LeakyReLU(s1 + s2[j]) : -9e15 ),  j = FR(r) + 4*lh
-__device__ __forceinline__ void attn_weights(T16 &alpha, float s1, const float (&s2)[16], unsigned amask, float slope) {
+// alpha[r] = softmax_j( mask ? LeakyReLU(s1 + s2[j]) : -inf ),  j = FR(r) + 4*lh
+// s1, s2 arrive scaled by log2(e) (api.hip v2_gat folds the factor into the logit weights; LeakyReLU commutes with a
+// positive factor), so the softmax is exp2(e - max) with no multiply; mb[r] = 0 / -inf is the mask as an addend, built once
+// per graph call instead of a bit test per head and row.  (The reference masks with -9e15: exp() of either is exactly 0.)
+__device__ __forceinline__ void attn_mask_bias(float (&mb)[16], unsigned amask) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mb[r] = ((amask >> r) & 1u) ? 0.f : -INFINITY;
+}
+__device__ __forceinline__ void attn_weights(T16 &alpha, float s1, const float (&s2)[16], const float (&mb)[16], float slope) {
     float e[16];
     float mx = -INFINITY;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        e[r] = ((amask >> r) & 1u) ? lrelu(s1 + s2[r], slope) : -9e15f;
+        e[r] = lrelu(s1 + s2[r], slope) + mb[r];
         mx = fmaxf(mx, e[r]);
     }
-    mx = hmax(mx);
+    mx = hmax(mx);          // finite: a row is always its own neighbour, in one of the two halves
     float sum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        e[r] = fexp(e[r] - mx);
+        e[r] = __builtin_amdgcn_exp2f(e[r] - mx);
         sum += e[r];
     }
     sum = hsum(sum);
@@ -267,6 +274,8 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
         for (int p = 0; p < 4; ++p) xch[p * 32 + lc] = sf[0][p];
     }
     __syncthreads();
+    float mb[16];
+    attn_mask_bias(mb, amask);
     T16 x2[1];
     zero(x2);
 #pragma unroll
@@ -275,7 +284,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
         for (int r = 0; r < 16; ++r) s2[r] = xch[p * 32 + FR(r) + 4 * lh];
         T16 alpha;
-        attn_weights(alpha, s1[p], s2, amask, slope);
+        attn_weights(alpha, s1[p], s2, mb, slope);
         const bool mine = (lc >> 3) == p;     // this lane's feature belongs to head p
 #pragma unroll
         for (int r = 0; r < 16; ++r) x2[0] = MFMA(mine ? whT[0][r] : 0.f, alpha[r], x2[0]);
@@ -294,7 +303,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
     for (int r = 0; r < 16; ++r) s2o[r] = xch[FR(r) + 4 * lh];
     T16 alpha;
-    attn_weights(alpha, t1, s2o, amask, slope);
+    attn_weights(alpha, t1, s2o, mb, slope);
     zero(out);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {      // one output tile at a time: Wh2^T tile -> aggregation (keeps 16, not NT*16, registers live)

@@ -411,8 +411,10 @@ DnGru pack_gru(Packer &pk, int l, int R, int H) {
 // ---- register-resident kernel (rollout_v2.hip): same tensors, MFMA-chain packing -------------
 // Npad / Gpad / SegSpec.kpad: sizes the segment is padded to (zeros), so that the layout of an instantiation does not
 // depend on g_dim or n_max_agents (params_v2.h v2_layout)
+// logits: the layer feeds a softmax over its N outputs and nothing else - weights and bias are scaled by log2(e) (the
+// kernels' softmax is exp2(x - max)) and the bias of the padded outputs is -inf, so they come out as exactly 0 without a mask.
 V2Lin v2_linear(Packer &pk, const std::string &name, int N, int Ktot, std::vector<SegSpec> segs, int gcol0 = -1, int G = 0,
-                int Npad = 0, int Gpad = 0) {
+                int Npad = 0, int Gpad = 0, bool logits = false) {
     V2Lin L;
     L.w[0] = L.w[1] = L.w[2] = 0;
     L.bias = L.gather = -1;
@@ -421,12 +423,14 @@ V2Lin v2_linear(Packer &pk, const std::string &name, int N, int Ktot, std::vecto
     if (!W || !B) return L;
     const float *w = W->p, *b = B->p;
     const int Np = std::max(N, Npad);
+    const float sc = logits ? 1.44269504088896340736f : 1.0f;
     for (size_t s = 0; s < segs.size(); ++s) {
         const int c0 = segs[s].col0;
         const int Ks = segs[s].K;
-        L.w[s] = pk.chain([=](int n, int k) { return (n < N && k < Ks) ? w[(size_t)n * Ktot + c0 + k] : 0.f; }, Np, std::max(Ks, segs[s].kpad));
+        L.w[s] = pk.chain([=](int n, int k) { return (n < N && k < Ks) ? sc * w[(size_t)n * Ktot + c0 + k] : 0.f; }, Np, std::max(Ks, segs[s].kpad));
     }
-    L.bias = pk.vec([=](int n) { return b[n]; }, N, pad32(Np));
+    if (logits) L.bias = pk.vec([=](int n) { return n < N ? sc * b[n] : -INFINITY; }, pad32(Np), pad32(Np));
+    else L.bias = pk.vec([=](int n) { return b[n]; }, N, pad32(Np));
     // one-hot input: row g of the table = column gcol0 + g of the weight PLUS the bias (v2_common.h finish<> loads one row)
     if (gcol0 >= 0) L.gather = pk.gather([=](int n, int g) { return w[(size_t)n * Ktot + gcol0 + g] + b[n]; }, N, G, Gpad);
     return L;
@@ -688,10 +692,10 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
     }
     if (dag && !ext) {
         W.dec_goal0 = v2_linear(pk, "dec_goal.0", H, Dd + R + G, {{0, Dd, DP}, {Dd, R}}, Dd + R, G, 0, GP);
-        W.dec_goal2 = v2_linear(pk, "dec_goal.2", G, H, {{0, H}}, -1, 0, GP);
+        W.dec_goal2 = v2_linear(pk, "dec_goal.2", G, H, {{0, H}}, -1, 0, GP, 0, true);
         W.g_goal = c.graph_model == DAGNET_GRAPH_GCN ? v2_gcn(pk, "graph_goals", G, G, c.graph_hid, GP)
                                                      : v2_gat(pk, "graph_goals", G, G, c.graph_hid, c.n_heads, GP);
-        W.lg_goals = v2_linear(pk, "lg_goals.0", G, 2 * G, {{0, G, GP}, {G, G, GP}}, -1, 0, GP);
+        W.lg_goals = v2_linear(pk, "lg_goals.0", G, 2 * G, {{0, G, GP}, {G, G, GP}}, -1, 0, GP, 0, true);
     }
 }
 

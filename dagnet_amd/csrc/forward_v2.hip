@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
             zero(decg);
             pre = mm<GT, 2, false>(decg, wp, W.dec_goal2.w[0], tg, lane, pre, W.lg_goals.w[0]);
             finish<0, GT>(decg, wp, W.dec_goal2, 0, lh);
-            softmax_feat<GT>(decg, R.G, lh);
+            softmax_feat<GT>(decg);
             T16 gc[GT];
             zero(gc);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.g_goal.heads);
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
             else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1]);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.phi_x2.w[0]);
             finish<0, GT>(gc, wp, W.lg_goals, 0, lh);
-            softmax_feat<GT>(gc, R.G, lh);
+            softmax_feat<GT>(gc);
             // cross_entropy -= sum(g_t * g_combined)   (probabilities, models/dagnet/model.py:162)
             float pv = 0.f;
 #pragma unroll

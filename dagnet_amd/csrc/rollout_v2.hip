@@ -211,7 +211,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             start<GT>(decg, wp, W.dec_goal2, 0, lh);
             pre = mm<GT, 2, false>(decg, wp, W.dec_goal2.w[0], tg, lane, pre, W.lg_goals.w[0]);
             activate<0, GT>(decg);
-            softmax_feat<GT>(decg, R.G, lh);
+            softmax_feat<GT>(decg);
             PH(1);
             // lg_goals = W1.dec_g + W2.g_graph: the dec_g half runs before the graph so that dec_g is dead
             // once the graph has consumed it (peak registers: gc + gg instead of dec_g + gg + gc)
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             PH(2);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.prior0.w[0]);
             activate<0, GT>(gc);
-            softmax_feat<GT>(gc, R.G, lh);
+            softmax_feat<GT>(gc);
             // categorical draw: argmax_g exp(p_g) / q_g, q ~ Exp(1).  Branch-free (selects only): features are visited in
             // increasing order within a lane, so a strict '>' keeps the first maximum; out-of-range features score -1.
             float best = -1.f;

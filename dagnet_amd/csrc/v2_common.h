@@ -195,24 +195,23 @@ __device__ __forceinline__ void finish(T16 (&x)[NT], const WBuf &wp, const V2Lin
     activate<ACT, NT>(x);
 }
 
-// softmax over the first G features of an S-layout row (features >= G are set to 0)
+// softmax over the features of an S-layout row whose logits arrive in the log2 domain with -inf in the padded features
+// (api.hip v2_linear, logits = true): no mask, exp2(x - max) with no multiply; padded features come out as exactly 0
 template <int NT>
-__device__ __forceinline__ void softmax_feat(T16 (&x)[NT], int G, int lh) {
+__device__ __forceinline__ void softmax_feat(T16 (&x)[NT]) {
     float mx = -INFINITY;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (nt * 32 + FR(r) + 4 * lh < G) mx = fmaxf(mx, x[nt][r]);
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, x[nt][r]);
     mx = hmax(mx);
     float sum = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = (nt * 32 + FR(r) + 4 * lh < G) ? fexp(x[nt][r] - mx) : 0.f;
-            x[nt][r] = e;
-            sum += e;
+            x[nt][r] = __builtin_amdgcn_exp2f(x[nt][r] - mx);
+            sum += x[nt][r];
         }
     sum = hsum(sum);
     const float inv = frcp(sum);

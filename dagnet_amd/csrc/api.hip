@@ -451,6 +451,7 @@ V2Lin v2_pair(Packer &pk, const std::string &a, const std::string &b, int Z, int
 
 // pad: nin and nout are padded to this many features (the goal graph: V2_GT tiles whatever g_dim is)
 static const double kLog2e = 1.4426950408889634074;
+static const double kTanhScale = 2.0 * kLog2e, kSigmScale = -kLog2e;   // v2_common.h tanh2() / sigm2()
 V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, int P, int pad = 0) {
     V2Gat g;
     memset(&g, 0, sizeof(g));
@@ -498,7 +499,8 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
             const int c = i % ld, row = i / ld;
             if (c >= nout) return 0.0f;
             const float sc = gp[c] / sqrtf(vp[c] + 1e-5f);
-            return row == 0 ? sc : bp[c] - mp[c] * sc;
+            // x 2 log2(e): the kernels' tanh2() takes its argument pre-scaled (v2_common.h)
+            return (float)(kTanhScale * (row == 0 ? sc : bp[c] - mp[c] * sc));
         },
         2 * ld, 2 * ld);
     return g;
@@ -519,7 +521,7 @@ V2Gat v2_gcn(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     const int ninp = std::max(nin, pad), noutp = std::max(nout, pad);
     g.heads = pk.chain([=](int n, int k) { return k < nin ? w1[(size_t)k * F + n] : 0.f; }, F, ninp);
     g.out = pk.chain([=](int n, int k) { return n < nout ? w2[(size_t)k * nout + n] : 0.f; }, noutp, F);
-    auto fold = [&](const std::string &bn, int n, const float *bias, int ld) {
+    auto fold = [&](const std::string &bn, int n, const float *bias, int ld, double act) {
         const Tensor *ga = pk.get(bn + ".weight", {n}), *be = pk.get(bn + ".bias", {n});
         const Tensor *mu = pk.get(bn + ".running_mean", {n}), *var = pk.get(bn + ".running_var", {n});
         if (!ga || !be || !mu || !var) return -1;
@@ -529,12 +531,12 @@ V2Gat v2_gcn(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
                 const int c = i % ld, row = i / ld;
                 if (c >= n) return 0.0f;
                 const float sc = gp[c] / sqrtf(vp[c] + 1e-5f);
-                return row == 0 ? sc : ((bias ? bias[c] : 0.f) - mp[c]) * sc + bp[c];
+                return (float)(act * (row == 0 ? sc : ((bias ? bias[c] : 0.f) - mp[c]) * sc + bp[c]));
             },
             2 * ld, 2 * ld);
     };
-    g.fold = fold(prefix + ".bn1", F, b1, 32);
-    g.bn = fold(prefix + ".bn2", nout, b2, pad32(noutp));
+    g.fold = fold(prefix + ".bn1", F, b1, 32, 1.0);
+    g.bn = fold(prefix + ".bn2", nout, b2, pad32(noutp), kTanhScale);       // layer 2 ends in tanh2()
     return g;
 }
 
@@ -549,13 +551,16 @@ V2Gru v2_gru(Packer &pk, int l, int R, int H) {
     const Tensor *Bh = pk.get("rnn.bias_hh_l" + sl, {3 * R});
     if (!Wi || !Wh || !Bi || !Bh) return g;
     const float *wi = Wi->p, *wh = Wh->p, *bi = Bi->p, *bh = Bh->p;
+    // gate pre-activations come out already scaled for sigm2() / tanh2() (v2_common.h): r, z by -log2(e); both halves of
+    // the candidate (W_in x + b_in and W_hn h + b_hn, the latter multiplied by r in between) by 2 log2(e)
     auto mk = [&](V2Lin &L, int gate, bool with_x, bool with_h) {
         L.w[0] = L.w[1] = L.w[2] = 0;
         L.gather = -1;
         int s = 0;
-        if (with_x) L.w[s++] = pk.chain([=](int n, int k) { return wi[(size_t)(gate * R + n) * Kin + k]; }, R, Kin);
-        if (with_h) L.w[s++] = pk.chain([=](int n, int k) { return wh[(size_t)(gate * R + n) * R + k]; }, R, R);
-        L.bias = pk.vec([=](int n) { return (with_x ? bi[gate * R + n] : 0.f) + (with_h ? bh[gate * R + n] : 0.f); }, R, pad32(R));
+        const double a = gate == 2 ? kTanhScale : kSigmScale;
+        if (with_x) L.w[s++] = pk.chain([=](int n, int k) { return (float)(a * wi[(size_t)(gate * R + n) * Kin + k]); }, R, Kin);
+        if (with_h) L.w[s++] = pk.chain([=](int n, int k) { return (float)(a * wh[(size_t)(gate * R + n) * R + k]); }, R, R);
+        L.bias = pk.vec([=](int n) { return (float)(a * ((with_x ? bi[gate * R + n] : 0.f) + (with_h ? bh[gate * R + n] : 0.f))); }, R, pad32(R));
     };
     mk(g.r, 0, true, true);
     mk(g.z, 1, true, true);

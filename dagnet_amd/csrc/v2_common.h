@@ -52,13 +52,13 @@ struct WBuf {
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.69314718055994530942f; }
-__device__ __forceinline__ float ftanh(float x) {
-    const float xc = fminf(fmaxf(x, -15.f), 15.f);
-    return 1.0f - 2.0f * frcp(1.0f + fexp(2.0f * xc));
-}
-// 0 < s < 1: max(v, s v) as one v_med3_f32 (fmaxf would first canonicalise v: a third instruction per element)
+// lrelu: 0 < s < 1: max(v, s v)
 __device__ __forceinline__ float lrelu(float v, float s) { return __builtin_amdgcn_fmed3f(v, v * s, INFINITY); }
-__device__ __forceinline__ float sigm(float v) { return frcp(1.0f + fexp(-v)); }
+// sigmoid / tanh of pre-activations that arrive ALREADY scaled (api.hip folds the factors into the packed weights, biases
+// and BatchNorm tables): sigm2(v) = sigmoid(x) for v = -log2(e) x, tanh2(v) = tanh(x) for v = 2 log2(e) x.  No clamp:
+// exp2 overflows to +inf, whose reciprocal is 0, and underflows to 0 - both limits come out exactly.
+__device__ __forceinline__ float sigm2(float v) { return frcp(1.0f + __builtin_amdgcn_exp2f(v)); }
+__device__ __forceinline__ float tanh2(float v) { return 1.0f - 2.0f * frcp(1.0f + __builtin_amdgcn_exp2f(v)); }
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32); }
 __device__ __forceinline__ int xhalf(int v) { return __shfl_xor(v, 32); }
 // max / sum over the two lane halves, the result in both: one v_permlane32_swap (gfx950, a VALU instruction) instead of a
@@ -324,7 +324,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const float v = out[nt][4 * a + i] * g4[i] + b4[i];
-                out[nt][4 * a + i] = ftanh(v);      // padded features: scale = shift = 0 -> tanh(0) = 0
+                out[nt][4 * a + i] = tanh2(v);      // padded features: scale = shift = 0 -> tanh(0) = 0
             }
         }
     return pre;
@@ -372,7 +372,7 @@ __device__ __forceinline__ WBlk gcn(const T16 (&x)[KT], T16 (&out)[NT], const WB
             const float4 sc = wp.ld4(lh * 16, Gw.bn + fs), sh = wp.ld4(lh * 16, Gw.bn + NT * 32 + fs);
             const float g4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {sh.x, sh.y, sh.z, sh.w};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) out[nt][4 * a + i] = ftanh(out[nt][4 * a + i] * g4[i] + b4[i]);
+            for (int i = 0; i < 4; ++i) out[nt][4 * a + i] = tanh2(out[nt][4 * a + i] * g4[i] + b4[i]);
         }
     return pre;
 }
@@ -420,16 +420,16 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const float4 b = bias4(1, Gw.r.bias, nt * 32 + 8 * a);
-            tt[4 * a + 0] *= sigm(acc[0][4 * a + 0] + b.x); tt[4 * a + 1] *= sigm(acc[0][4 * a + 1] + b.y);
-            tt[4 * a + 2] *= sigm(acc[0][4 * a + 2] + b.z); tt[4 * a + 3] *= sigm(acc[0][4 * a + 3] + b.w);
+            tt[4 * a + 0] *= sigm2(acc[0][4 * a + 0] + b.x); tt[4 * a + 1] *= sigm2(acc[0][4 * a + 1] + b.y);
+            tt[4 * a + 2] *= sigm2(acc[0][4 * a + 2] + b.z); tt[4 * a + 3] *= sigm2(acc[0][4 * a + 3] + b.w);
         }
         zero(acc);
         pre = mm<1, KX, false>(acc, wp, Gw.ni.w[0] + ox, xin, lane, pre, Gw.z.w[0] + ox);
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const float4 b = bias4(2, Gw.ni.bias, nt * 32 + 8 * a);
-            ng[4 * a + 0] = ftanh((acc[0][4 * a + 0] + b.x) + tt[4 * a + 0]); ng[4 * a + 1] = ftanh((acc[0][4 * a + 1] + b.y) + tt[4 * a + 1]);
-            ng[4 * a + 2] = ftanh((acc[0][4 * a + 2] + b.z) + tt[4 * a + 2]); ng[4 * a + 3] = ftanh((acc[0][4 * a + 3] + b.w) + tt[4 * a + 3]);
+            ng[4 * a + 0] = tanh2((acc[0][4 * a + 0] + b.x) + tt[4 * a + 0]); ng[4 * a + 1] = tanh2((acc[0][4 * a + 1] + b.y) + tt[4 * a + 1]);
+            ng[4 * a + 2] = tanh2((acc[0][4 * a + 2] + b.z) + tt[4 * a + 2]); ng[4 * a + 3] = tanh2((acc[0][4 * a + 3] + b.w) + tt[4 * a + 3]);
         }
         zero(acc);
         pre = mm<1, KX, false>(acc, wp, Gw.z.w[0] + ox, xin, lane, pre, Gw.z.w[1] + oh);
@@ -441,7 +441,7 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 4 * a + i;
-                const float zg = sigm(acc[0][r] + b4[i]);
+                const float zg = sigm2(acc[0][r] + b4[i]);
                 hn[nt][r] = (1.0f - zg) * ng[r] + zg * h[nt][r];
             }
         }

@@ -480,7 +480,15 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
             return (float)(acc * kLog2e);       // logits in the log2 domain: the kernels' softmax is exp2(e - max)
         },
         2 * P, ninp);
-    g.out = pk.chain([=](int n, int k) { return n < nout ? wo[(size_t)k * nout + n] : 0.f; }, noutp, P * F);
+    const Tensor *ga = pk.get(prefix + ".bn1.weight", {nout}), *be = pk.get(prefix + ".bn1.bias", {nout});
+    const Tensor *mu = pk.get(prefix + ".bn1.running_mean", {nout}), *var = pk.get(prefix + ".bn1.running_var", {nout});
+    if (!ga || !be || !mu || !var) return g;
+    const float *gp = ga->p, *bp = be->p, *mp = mu->p, *vp = var->p;
+    // eval-mode BatchNorm y = x * scale + shift and the factor 2 log2(e) of the kernels' tanh2() (v2_common.h): the scale
+    // goes into the out_att weights (the attention sums over rows, the scale is per feature), the shift into g.bn
+    g.out = pk.chain(
+        [=](int n, int k) { return n < nout ? (float)(kTanhScale * (gp[n] / sqrtf(vp[n] + 1e-5f)) * wo[(size_t)k * nout + n]) : 0.f; },
+        noutp, P * F);
     g.fold_out = pk.chain(
         [=](int q, int k) {
             double acc = 0.0;
@@ -488,21 +496,14 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
             return (float)(acc * kLog2e);
         },
         2, P * F);
-    const Tensor *ga = pk.get(prefix + ".bn1.weight", {nout}), *be = pk.get(prefix + ".bn1.bias", {nout});
-    const Tensor *mu = pk.get(prefix + ".bn1.running_mean", {nout}), *var = pk.get(prefix + ".bn1.running_var", {nout});
-    if (!ga || !be || !mu || !var) return g;
-    const float *gp = ga->p, *bp = be->p, *mp = mu->p, *vp = var->p;
     const int ld = pad32(noutp);
-    // eval-mode BatchNorm folded to y = x * scale + shift
     g.bn = pk.vec(
-        [=](int i) {
-            const int c = i % ld, row = i / ld;
+        [=](int c) {
             if (c >= nout) return 0.0f;
             const float sc = gp[c] / sqrtf(vp[c] + 1e-5f);
-            // x 2 log2(e): the kernels' tanh2() takes its argument pre-scaled (v2_common.h)
-            return (float)(kTanhScale * (row == 0 ? sc : bp[c] - mp[c] * sc));
+            return (float)(kTanhScale * (bp[c] - mp[c] * sc));
         },
-        2 * ld, 2 * ld);
+        ld, 2 * ld);        // second row unused (params_v2.h keeps one table size for GAT and GCN)
     return g;
 }
 

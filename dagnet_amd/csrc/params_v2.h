@@ -21,7 +21,7 @@ struct V2Gat {
     int32_t fold;      // chain-packed [1 tile out][KT]: features 0..P-1 = W.a_src, P..2P-1 = W.a_dst
     int32_t out;       // chain-packed [NT][1]
     int32_t fold_out;  // chain-packed [1][1]: feature 0 = W_out.a_src, 1 = W_out.a_dst
-    int32_t bn;        // raw [4][NT*32]: gamma, beta, mean, sqrt(var+eps)  (zero padded per row)
+    int32_t bn;        // [2][NT*32]: GAT row 0 = folded BatchNorm shift (the scale sits in `out`), row 1 unused
     int32_t nout;
 };
 

@@ -303,7 +303,15 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     for (int r = 0; r < 16; ++r) s2o[r] = xch[FR(r) + 4 * lh];
     T16 alpha;
     attn_weights(alpha, t1, s2o, mb, slope);
-    zero(out);
+    // eval BatchNorm folded away (api.hip v2_gat): its scale (and tanh2's factor) sits in the out_att weights - a factor per
+    // output feature commutes with the aggregation over rows - and its shift is the accumulators' initial value
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 sh = wp.ld4(lh * 16, Gw.bn + nt * 32 + 8 * a);
+            out[nt][4 * a + 0] = sh.x; out[nt][4 * a + 1] = sh.y; out[nt][4 * a + 2] = sh.z; out[nt][4 * a + 3] = sh.w;
+        }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {      // one output tile at a time: Wh2^T tile -> aggregation (keeps 16, not NT*16, registers live)
         T16 wh2T[1];
@@ -312,21 +320,11 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], alpha[r], out[nt]);
     }
-    // BatchNorm1d (running statistics) + tanh; padded features stay 0
+    // tanh; padded features (weights and shift 0) stay 0
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int fs = nt * 32 + 8 * a;
-            const float4 sc = wp.ld4(lh * 16, Gw.bn + fs);               // gamma / sqrt(var + eps)
-            const float4 sh = wp.ld4(lh * 16, Gw.bn + NT * 32 + fs);     // beta - mean * scale
-            const float g4[4] = {sc.x, sc.y, sc.z, sc.w}, b4[4] = {sh.x, sh.y, sh.z, sh.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float v = out[nt][4 * a + i] * g4[i] + b4[i];
-                out[nt][4 * a + i] = tanh2(v);      // padded features: scale = shift = 0 -> tanh(0) = 0
-            }
-        }
+        for (int r = 0; r < 16; ++r) out[nt][r] = tanh2(out[nt][r]);
     return pre;
 }
 
@@ -398,6 +396,15 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
         if constexpr (LB) return *reinterpret_cast<const float4 *>(lb + gate * 64 + f + 4 * lh);
         else return wp.ld4(lh * 16, goff + f);
     };
+    // a gate's bias is the initial value of its accumulator (read from LDS / L2 while the previous gate's MFMAs run), not
+    // an addition after its last MFMA
+    auto init = [&](T16 &acc, int gate, int goff, int nt) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 b = bias4(gate, goff, nt * 32 + 8 * a);
+            acc[4 * a + 0] = b.x; acc[4 * a + 1] = b.y; acc[4 * a + 2] = b.z; acc[4 * a + 3] = b.w;
+        }
+    };
     T16 hn[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
@@ -406,44 +413,25 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
         // weights of a gate are packed per output tile: offset of tile nt = nt * KT * 1024 floats
         const int ox = nt * KX * 1024, oh = nt * 2 * 1024;
         T16 acc[1], tt, ng;
-        zero(acc);
+        init(acc[0], 0, Gw.nh.bias, nt);
         pre = mm<1, 2, false>(acc, wp, Gw.nh.w[0] + oh, h, lane, pre, Gw.r.w[0] + ox);
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 b = bias4(0, Gw.nh.bias, nt * 32 + 8 * a);
-            tt[4 * a + 0] = acc[0][4 * a + 0] + b.x; tt[4 * a + 1] = acc[0][4 * a + 1] + b.y;
-            tt[4 * a + 2] = acc[0][4 * a + 2] + b.z; tt[4 * a + 3] = acc[0][4 * a + 3] + b.w;
-        }
-        zero(acc);
+        tt = acc[0];
+        init(acc[0], 1, Gw.r.bias, nt);
         pre = mm<1, KX, false>(acc, wp, Gw.r.w[0] + ox, xin, lane, pre, Gw.r.w[1] + oh);
         pre = mm<1, 2, false>(acc, wp, Gw.r.w[1] + oh, h, lane, pre, Gw.ni.w[0] + ox);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 b = bias4(1, Gw.r.bias, nt * 32 + 8 * a);
-            tt[4 * a + 0] *= sigm2(acc[0][4 * a + 0] + b.x); tt[4 * a + 1] *= sigm2(acc[0][4 * a + 1] + b.y);
-            tt[4 * a + 2] *= sigm2(acc[0][4 * a + 2] + b.z); tt[4 * a + 3] *= sigm2(acc[0][4 * a + 3] + b.w);
-        }
-        zero(acc);
+        for (int r = 0; r < 16; ++r) tt[r] *= sigm2(acc[0][r]);
+        init(acc[0], 2, Gw.ni.bias, nt);
         pre = mm<1, KX, false>(acc, wp, Gw.ni.w[0] + ox, xin, lane, pre, Gw.z.w[0] + ox);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 b = bias4(2, Gw.ni.bias, nt * 32 + 8 * a);
-            ng[4 * a + 0] = tanh2((acc[0][4 * a + 0] + b.x) + tt[4 * a + 0]); ng[4 * a + 1] = tanh2((acc[0][4 * a + 1] + b.y) + tt[4 * a + 1]);
-            ng[4 * a + 2] = tanh2((acc[0][4 * a + 2] + b.z) + tt[4 * a + 2]); ng[4 * a + 3] = tanh2((acc[0][4 * a + 3] + b.w) + tt[4 * a + 3]);
-        }
-        zero(acc);
+        for (int r = 0; r < 16; ++r) ng[r] = tanh2(acc[0][r] + tt[r]);
+        init(acc[0], 3, Gw.z.bias, nt);
         pre = mm<1, KX, false>(acc, wp, Gw.z.w[0] + ox, xin, lane, pre, Gw.z.w[1] + oh);
         pre = mm<1, 2, false>(acc, wp, Gw.z.w[1] + oh, h, lane, pre, nt == 0 ? Gw.nh.w[0] + 2 * 1024 : next_off);
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 b = bias4(3, Gw.z.bias, nt * 32 + 8 * a);
-            const float b4[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * a + i;
-                const float zg = sigm2(acc[0][r] + b4[i]);
-                hn[nt][r] = (1.0f - zg) * ng[r] + zg * h[nt][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const float zg = sigm2(acc[0][r]);
+            hn[nt][r] = zg * (h[nt][r] - ng[r]) + ng[r];        // (1 - z) n + z h
         }
     }
     h[0] = hn[0];

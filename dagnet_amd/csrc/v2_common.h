@@ -230,7 +230,10 @@ __device__ __forceinline__ void attn_mask_bias(float (&mb)[16], unsigned amask) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) mb[r] = ((amask >> r) & 1u) ? 0.f : -INFINITY;
 }
-__device__ __forceinline__ void attn_weights(T16 &alpha, float s1, const float (&s2)[16], const float (&mb)[16], float slope) {
+// NORM = false: alpha is left unnormalised (exp2(e - max)) and 1 / sum is returned, for the caller to apply to the
+// aggregated result - a factor per row commutes with the aggregation, and the MFMAs need not wait for sum -> rcp -> multiply
+template <bool NORM = true>
+__device__ __forceinline__ float attn_weights(T16 &alpha, float s1, const float (&s2)[16], const float (&mb)[16], float slope) {
     float e[16];
     float mx = -INFINITY;
 #pragma unroll
@@ -248,7 +251,8 @@ __device__ __forceinline__ void attn_weights(T16 &alpha, float s1, const float (
     sum = hsum(sum);
     const float inv = frcp(sum);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) alpha[r] = e[r] * inv;
+    for (int r = 0; r < 16; ++r) alpha[r] = NORM ? e[r] * inv : e[r];
+    return inv;
 }
 
 // Dense GAT (P heads of F features with P*F = 32 -> out_att -> BatchNorm(eval) -> tanh) on the tile.
@@ -277,19 +281,24 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     attn_mask_bias(mb, amask);
     T16 x2[1];
     zero(x2);
+    float inv[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         float s2[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) s2[r] = xch[p * 32 + FR(r) + 4 * lh];
         T16 alpha;
-        attn_weights(alpha, s1[p], s2, mb, slope);
+        inv[p] = attn_weights<false>(alpha, s1[p], s2, mb, slope);
         const bool mine = (lc >> 3) == p;     // this lane's feature belongs to head p
 #pragma unroll
         for (int r = 0; r < 16; ++r) x2[0] = MFMA(mine ? whT[0][r] : 0.f, alpha[r], x2[0]);
     }
+    // head p's features 8p .. 8p+7 are registers 4p .. 4p+3 of this lane's row: its softmax denominator is applied here
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x2[0][r] = x2[0][r] > 0.f ? x2[0][r] : fexp(x2[0][r]) - 1.0f;     // ELU
+    for (int r = 0; r < 16; ++r) {
+        const float v = x2[0][r] * inv[r >> 2];
+        x2[0][r] = v > 0.f ? v : fexp(v) - 1.0f;     // ELU
+    }
     // out_att
     T16 sf2[1];
     zero(sf2);

@@ -311,16 +311,10 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
     for (int r = 0; r < 16; ++r) s2o[r] = xch[FR(r) + 4 * lh];
     T16 alpha;
-    attn_weights(alpha, t1, s2o, mb, slope);
+    const float invo = attn_weights<false>(alpha, t1, s2o, mb, slope);
     // eval BatchNorm folded away (api.hip v2_gat): its scale (and tanh2's factor) sits in the out_att weights - a factor per
-    // output feature commutes with the aggregation over rows - and its shift is the accumulators' initial value
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const float4 sh = wp.ld4(lh * 16, Gw.bn + nt * 32 + 8 * a);
-            out[nt][4 * a + 0] = sh.x; out[nt][4 * a + 1] = sh.y; out[nt][4 * a + 2] = sh.z; out[nt][4 * a + 3] = sh.w;
-        }
+    // output feature commutes with the aggregation over rows - and its shift is added with the softmax denominator
+    zero(out);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {      // one output tile at a time: Wh2^T tile -> aggregation (keeps 16, not NT*16, registers live)
         T16 wh2T[1];
@@ -333,7 +327,12 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[nt][r] = tanh2(out[nt][r]);
+        for (int a = 0; a < 4; ++a) {
+            const float4 sh = wp.ld4(lh * 16, Gw.bn + nt * 32 + 8 * a);
+            const float b4[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[nt][4 * a + i] = tanh2(out[nt][4 * a + i] * invo + b4[i]);
+        }
     return pre;
 }
 

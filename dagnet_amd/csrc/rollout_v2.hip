@@ -220,7 +220,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.g_goal.heads);
             T16 gg[GT];
             if constexpr (GM == 2) pre = gcn<GT, GT>(decg, gg, wp, W.g_goal, adjval, lane, pre, W.lg_goals.w[1]);
-            else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1]);
+            else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1], [&](int i) { PH(i); });
             PH(2);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.prior0.w[0]);
             activate<0, GT>(gc);

@@ -257,9 +257,13 @@ __device__ __forceinline__ float attn_weights(T16 &alpha, float s1, const float 
 
 // Dense GAT (P heads of F features with P*F = 32 -> out_att -> BatchNorm(eval) -> tanh) on the tile.
 // x: KT input tiles (S).  out: NT tiles (S).  xch: per-wave LDS scratch of >= 32*4 floats.
-template <int KT, int NT>
+struct NoProf {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+// ph: stage timer of the diagnostic build (rollout_v2.hip PH(), tools/phase_profile.py); a no-op otherwise
+template <int KT, int NT, class PF = NoProf>
 __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WBuf &wp, const V2Gat &Gw, unsigned amask,
-                                    float slope, float *xch, int lane, WBlk pre, int next_off) {
+                                    float slope, float *xch, int lane, WBlk pre, int next_off, PF ph = PF()) {
     const int lh = lane >> 5, lc = lane & 31;
     // Wh for all heads, transposed: lane = head feature, register = tile row
     T16 whT[1], sf[1];
@@ -268,6 +272,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     pre = mm<1, KT, true>(whT, wp, Gw.heads, x, lane, pre, Gw.fold);
     // s1[p] = a_src[p].Wh_row, s2[p] = a_dst[p].Wh_row through folded weights: features 0..3 / 4..7
     pre = mm<1, KT, false>(sf, wp, Gw.fold, x, lane, pre, Gw.fold_out);
+    ph(10);
     float s1[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) s1[p] = __shfl(sf[0][p], lc);          // half 0 holds features 0..3
@@ -279,6 +284,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     __syncthreads();
     float mb[16];
     attn_mask_bias(mb, amask);
+    ph(11);
     T16 x2[1];
     zero(x2);
     float inv[4];
@@ -293,6 +299,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
         for (int r = 0; r < 16; ++r) x2[0] = MFMA(mine ? whT[0][r] : 0.f, alpha[r], x2[0]);
     }
+    ph(12);
     // head p's features 8p .. 8p+7 are registers 4p .. 4p+3 of this lane's row: its softmax denominator is applied here
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -312,6 +319,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     for (int r = 0; r < 16; ++r) s2o[r] = xch[FR(r) + 4 * lh];
     T16 alpha;
     const float invo = attn_weights<false>(alpha, t1, s2o, mb, slope);
+    ph(13);
     // eval BatchNorm folded away (api.hip v2_gat): its scale (and tanh2's factor) sits in the out_att weights - a factor per
     // output feature commutes with the aggregation over rows - and its shift is added with the softmax denominator
     zero(out);
@@ -323,6 +331,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], alpha[r], out[nt]);
     }
+    ph(14);
     // tanh; padded features (weights and shift 0) stay 0
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -333,6 +342,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 #pragma unroll
             for (int i = 0; i < 4; ++i) out[nt][4 * a + i] = tanh2(out[nt][4 * a + i] * invo + b4[i]);
         }
+    ph(15);
     return pre;
 }
 

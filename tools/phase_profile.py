@@ -17,7 +17,9 @@ _capi._LIB_PATH = os.path.join(ROOT, "dagnet_amd", "_lib", "libdagnet_hip_prof.s
 import bench
 
 PHASES = ["0 d_t+adjacency", "1 dec_goal+softmax", "2 goal graph", "3 lg_goals+softmax+draw", "4 prior", "5 z",
-          "6 phi_z+dec+dec_mean", "7 phi_x", "8 GRU", "9 hidden graph+blend+xabs"]
+          "6 phi_z+dec+dec_mean", "7 phi_x", "8 GRU", "9 hidden graph+blend+xabs",
+          "10 goal GAT: heads+fold MFMAs", "11 goal GAT: s1/s2 exchange", "12 goal GAT: 4 heads softmax+aggregation",
+          "13 goal GAT: ELU+fold_out+out softmax", "14 goal GAT: out tiles", "15 goal GAT: shift+tanh"]
 
 
 def main():

@@ -42,6 +42,14 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     __shared__ float gbias[NL * GRU_BIAS_FLOATS];      // GRU gate biases (v2_common.h gru_bias_to_lds)
     float *pos = xch + 128;                 // [32][2] current absolute positions of the tile rows
     const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
+#ifdef DN_V2_STAGGER_SLOT
+    {   // same idea, deterministic: the wave in an odd hardware slot of its SIMD (HW_ID bits 3:0) starts half a step late;
+        // only the first round of waves needs it, a successor starts when its predecessor ends and inherits the offset
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4);
+        if ((slot & 1u) && blockIdx.x < 2048u)
+            for (unsigned i = 0; i < DN_V2_STAGGER_SLOT; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
 #ifdef DN_V2_STAGGER
     {   // de-synchronise the two waves of a SIMD: identical programs started together stay in lockstep and then want the
         // MFMA pipe, and later the VALU, at the same time; a pseudo-random start delay of up to ~one step breaks that

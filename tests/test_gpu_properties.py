@@ -385,3 +385,36 @@ def test_register_resident_kernel_with_any_goal_width(g_dim, cells):
     for gotv, wantv in ((k, wk), (n, wn), (c, wc)):
         assert float(gotv) == pytest.approx(float(wantv), rel=1e-4, abs=1e-5)
     assert (hh.cpu() - wh).abs().max() < 2e-4
+
+
+def test_saturated_gates_and_tanh_stay_exact():
+    """The register-resident kernels evaluate sigmoid / tanh as rcp(1 + exp2(v)) on pre-scaled arguments with no clamp
+    (v2_common.h sigm2 / tanh2): with GRU and graph BatchNorm weights blown up until exp2 overflows to +inf and underflows
+    to 0, the gates must come out as exactly 0 / 1 / -1 like torch's - no NaN, no inf, and the oracle's displacements on the
+    first steps."""
+    a, m, sd = _model("avrnn", n_layers=1)
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in sd:
+        if k.startswith("rnn.weight") or k.startswith("rnn.bias"):
+            sd[k] *= 400.0
+        if k.endswith("bn1.weight") or k.endswith("bn1.bias"):
+            sd[k] *= 300.0
+    m.load_state_dict(sd)
+    sizes, T, seed = [10, 7, 1, 10], 8, 77
+    batch = syn.make_batch(sizes, 5, T, seed)
+    obs, gt, obs_rel, gt_rel, og, pg, sse = batch
+    N = obs.shape[1]
+    assert m.hip_plan(DEV, scene_ptr_from_sse(sse), 1).info()["sample_kernel"].startswith("rollout_v2")
+    h = syn.uniform_noise(seed, "h0", (1, N, 64)) - 0.5
+    eps = syn.uniform_noise(seed, "eps", (1, T, N, a.z_dim))
+    cfg = orc.make_cfg(n_layers=1)
+    with torch.no_grad():
+        want = orc.avrnn_sample(sd, cfg, T, h, obs[-1], sse, eps[0])
+    d = [t.to(DEV) for t in batch]
+    got = _sample_k("avrnn", m, 1, T, h.to(DEV), d, eps=eps.to(DEV))[0].cpu()
+    assert torch.isfinite(got).all() and got.abs().max().item() < 10.0
+    # hard-limited gates with gains in the hundreds amplify rounding noise step by step (the oracle against itself in
+    # another summation order drifts the same way), so the comparison is on the steps before that sets in: t = 0 (no GRU
+    # yet) and t = 1 (one saturated GRU step and one saturated graph BatchNorm + tanh behind it)
+    err = (got[:2] - want[:2]).abs() - (DISP_ATOL + DISP_RTOL * want[:2].abs())
+    assert err.max().item() <= 0, f"max abs diff {(got[:2] - want[:2]).abs().max().item():.3e}"

@@ -22,7 +22,7 @@ OP_EXPORTS = (
     "dagnet_op_gemm", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
     "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
-    "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
+    "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
     "dagnet_op_gat_attn_fwd", "dagnet_op_gat_attn_bwd", "dagnet_op_adj_matmul", "dagnet_op_disposition", "dagnet_op_sumsq",
     "dagnet_op_adam",
 )
@@ -58,6 +58,7 @@ def _lib():
         lib.dagnet_op_col_workspace.argtypes = [i64, i32]
         lib.dagnet_op_col_workspace.restype = i64
         lib.dagnet_op_colsum.argtypes = [i64, i32, vp, i64, vp, i32, vp, vp]
+        lib.dagnet_op_colsum_static.argtypes = [i64, i32, vp, i64, vp, i32, vp]
         lib.dagnet_op_bn_fwd.argtypes = [i64, i32, vp, i64, vp, vp, f32, f32, i32, vp, i64, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_bn_bwd.argtypes = [i64, i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, vp, i64, vp, vp, i32, vp, vp, vp]
         lib.dagnet_op_gat_attn_fwd.argtypes = [vp, vp, i64, vp, i64, vp, i32, i32, f32, i32, vp, i64, vp]
@@ -138,6 +139,14 @@ def colsum(X, out, accumulate=False):
     M, N = X.shape
     ws = _ws(X.device, _lib().dagnet_op_col_workspace(M, N))
     _check(_lib().dagnet_op_colsum(M, N, x, ldx, _p(out), int(accumulate), _p(ws), _stream(X.device)))
+
+
+def colsum_static(X, out, accumulate=False):
+    """colsum without a workspace tensor: the partial sums live in the library's static device array (at most 1024 columns;
+    nothing is allocated, so the call is safe under hipGraph capture).  Calls on one GPU must not overlap."""
+    (x, ldx) = _m(X, "X")
+    M, N = X.shape
+    _check(_lib().dagnet_op_colsum_static(M, N, x, ldx, _p(out), int(accumulate), _stream(X.device)))
 
 
 def copy2d(src, dst, accumulate=False):

@@ -1587,6 +1587,16 @@ extern "C" int dagnet_op_colsum(int64_t M, int32_t N, const float *X, int64_t ld
     HIP_TRY(dn_t_colsum(M, N, X, ldx, out, accumulate, workspace, OP_ST));
     return DAGNET_OK;
 }
+extern "C" int dn_t_colsum_static_max_cols(void);
+extern "C" hipError_t dn_t_colsum_static(int64_t, int, const float *, int64_t, float *, int, hipStream_t);
+extern "C" int dagnet_op_colsum_static(int64_t M, int32_t N, const float *X, int64_t ldx, float *out, int32_t accumulate, void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && (N == 0 || (out && (M == 0 || X))), "bad argument");
+    if (N > dn_t_colsum_static_max_cols())
+        return fail(DAGNET_ERR_CAPACITY, "dagnet_op_colsum_static: %d columns exceed the static scratch (at most %d); use dagnet_op_colsum "
+                    "with a caller workspace", N, dn_t_colsum_static_max_cols());
+    HIP_TRY(dn_t_colsum_static(M, N, X, ldx, out, accumulate, OP_ST));
+    return DAGNET_OK;
+}
 extern "C" int dagnet_op_bn_fwd(int64_t M, int32_t N, const float *X, int64_t ldx, const float *gamma, const float *beta, float eps,
                                 float momentum, int32_t tanh_out, float *Y, int64_t ldy, float *stat, float *run_mean, float *run_var,
                                 float *tmp, float *workspace, void *stream) {

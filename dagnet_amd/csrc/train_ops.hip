@@ -7,6 +7,7 @@
 // (scene_ptr, row -> scene, offsets of the compact block-diagonal adjacency).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 
 namespace tops {
 
@@ -630,6 +631,45 @@ static hipError_t col_reduce(int64_t M, int N, const float *X, int64_t ldx, cons
 // out[c] (+)= sum_m X[m][c]
 extern "C" hipError_t dn_t_colsum(int64_t M, int N, const float *X, int64_t ldx, float *out, int accumulate, float *part, hipStream_t st) {
     if (N == 0) return hipSuccess;
+    return col_reduce<0>(M, N, X, ldx, nullptr, nullptr, 0, nullptr, 0, 0, part, 1.0f, out, nullptr, accumulate, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dagnet_op_colsum_static: dn_t_colsum with the split partial sums in a file-scope device array instead of a caller
+// workspace, for callers that cannot allocate (HIP graph capture, tight serving loops).  Every GPU holds its own copy of
+// the array until the process ends; the host-side name `scratch` is only a handle for hipGetSymbolAddress, the kernels get
+// the per-device address.  Calls that overlap on one GPU (two streams) race on the array.
+// ---------------------------------------------------------------------------------------------
+#define DN_STATIC_COLS 1024                                   // widest matrix the static variant accepts
+#define DN_STATIC_FLOATS (512 * 2 * DN_STATIC_COLS)           // col_splits() <= 512 splits x 2 quantities x columns = 4 MiB
+static __device__ __align__(256) float scratch[DN_STATIC_FLOATS];
+
+#define DN_MAX_DEVICES 64
+static float *g_scratch_ptr[DN_MAX_DEVICES];                  // per device: address of that GPU's copy of `scratch`
+static std::mutex g_scratch_mu;
+
+extern "C" int dn_t_colsum_static_max_cols(void) { return DN_STATIC_COLS; }
+
+// -> hipErrorInvalidValue for N > DN_STATIC_COLS (the caller reports the limit); no allocation, no host synchronisation
+extern "C" hipError_t dn_t_colsum_static(int64_t M, int N, const float *X, int64_t ldx, float *out, int accumulate, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    if (N > DN_STATIC_COLS || (int64_t)col_splits(M) * 2 * N > DN_STATIC_FLOATS) return hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= DN_MAX_DEVICES) return hipErrorInvalidDevice;
+    float *part;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        if (!g_scratch_ptr[dev]) {                            // first call on this device, with this device current
+            void *p = nullptr;
+            e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+            if (e != hipSuccess) return e;
+            g_scratch_ptr[dev] = static_cast<float *>(p);
+        }
+        part = g_scratch_ptr[dev];
+    }
+    // every partial the second stage reads is written by the first stage of the same call: nothing to clear between calls
     return col_reduce<0>(M, N, X, ldx, nullptr, nullptr, 0, nullptr, 0, 0, part, 1.0f, out, nullptr, accumulate, st);
 }
 

@@ -244,6 +244,12 @@ int dagnet_op_sum(int64_t n, const float *x, float scale, float *out, int32_t ac
 int64_t dagnet_op_col_workspace(int64_t M, int32_t N);
 int dagnet_op_colsum(int64_t M, int32_t N, const float *X, int64_t ldx, float *out, int32_t accumulate, float *workspace,
                      void *stream);
+/* No counterpart in the reference: dagnet_op_colsum for callers that cannot allocate or pass a workspace (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same kernels and result as dagnet_op_colsum; the
+ * split partial sums live in a static device array of the library (4 MiB per GPU, held until the process ends), so N is
+ * limited to 1024 columns (DAGNET_ERR_CAPACITY beyond).  Calls no hipMalloc / hipFree and does not synchronise.  All calls
+ * on one GPU share that array: calls that overlap on one GPU (different streams) race. */
+int dagnet_op_colsum_static(int64_t M, int32_t N, const float *X, int64_t ldx, float *out, int32_t accumulate, void *stream);
 /* Replaces: nn.BatchNorm1d in train() mode followed by tanh (gat_model.py:21-22, gcn_model.py:15-19): batch statistics
  * over all M rows, running statistics updated in place (momentum, unbiased variance).  stat [2N] keeps mean | invstd,
  * tmp [2N] and sums [2N] are scratch. */

@@ -13,10 +13,12 @@ from ._runtime import HipBacked, infer_scene_ptr_from_adj, scene_ptr_from_sse
 
 
 class GraphAttentionLayer(nn.Module):
-    """Parameter container of one attention head (W [in,out], a [2*out,1]).
+    """One attention head (W [in,out], a [2*out,1]; gat_layers.py:5-40).
 
-    The reference evaluates a head on its own only through GAT.forward; here a head is a
-    parameter holder and ``GAT`` runs all heads + out_att + BN + tanh in one kernel."""
+    ``forward(input, adj)`` evaluates the head on its own: ``h = input W`` (fp32 MFMA GEMM), then per scene of the
+    block-diagonal ``adj`` the masked LeakyReLU logits, row softmax and ``attention @ h`` (+ ELU when ``concat``) in one
+    kernel - the reference's [N,N,2F] ``a_input`` tensor is never built.  Differentiable (the training operators of _ops).
+    Inside ``GAT`` all heads + out_att + BatchNorm + tanh run fused instead."""
 
     def __init__(self, in_features, out_features, alpha, concat=True):
         super().__init__()
@@ -29,10 +31,27 @@ class GraphAttentionLayer(nn.Module):
         self.a = nn.Parameter(torch.zeros(2 * out_features, 1))
         nn.init.xavier_uniform_(self.a.data, gain=1.414)
 
-    def forward(self, input, adj):
-        raise NotImplementedError(
-            "a single GraphAttentionLayer is not a separate kernel in the HIP path; call GAT.forward "
-            "(heads, out_att, BatchNorm and tanh are fused per scene)")
+    def forward(self, input, adj, seq_start_end=None):
+        """input [N,in], adj dense [N,N] block diagonal (or BlockDiagAdj) -> [N,out]."""
+        from . import _ops
+        plan, a = _layer_plan(input, adj, seq_start_end)
+        h = _ops.MatmulFn.apply(input.float(), self.W)
+        return _ops.GatAttnFn.apply(h, _ops.StackFn.apply(True, self.a), a, plan, 1, self.out_features, float(self.alpha),
+                                    bool(self.concat))
+
+
+def _layer_plan(x, adj, seq_start_end):
+    """Scene tables + adjacency operand (compact values or the dense matrix) for the stand-alone layers."""
+    from .adjacency_matrix import BlockDiagAdj
+    from .training import table_plan
+    if not x.is_cuda:
+        raise _capi.DagnetHipError(f"input lives on {x.device}; the HIP path needs a ROCm device and has no CPU fallback")
+    if isinstance(adj, BlockDiagAdj):
+        sp, a = adj.scene_ptr, adj.values.reshape(-1).float()
+    else:
+        sp = scene_ptr_from_sse(seq_start_end, x.shape[0]) if seq_start_end is not None else infer_scene_ptr_from_adj(adj)
+        a = adj.float().contiguous()
+    return table_plan(sp, x.device), a
 
 
 class GAT(nn.Module, HipBacked):

@@ -15,7 +15,9 @@ from .gat import _graph_module_forward
 
 
 class GraphConvolution(nn.Module):
-    """Parameter container (weight [in,out], bias [out]); evaluated inside GCN.forward."""
+    """One graph convolution (weight [in,out], bias [out]; gcn_layers.py:6-34): ``adj @ (input @ weight) + bias`` with the
+    adjacency VALUES as weights, per scene of the block-diagonal ``adj``.  Differentiable.  Inside ``GCN`` both layers and
+    their BatchNorms run fused instead."""
 
     def __init__(self, in_features, out_features, bias=True):
         super().__init__()
@@ -34,10 +36,12 @@ class GraphConvolution(nn.Module):
         if self.bias is not None:
             self.bias.data.uniform_(-stdv, stdv)
 
-    def forward(self, input, adj):
-        raise NotImplementedError(
-            "a single GraphConvolution is not a separate kernel in the HIP path; call GCN.forward "
-            "(both layers and their BatchNorms are fused per scene)")
+    def forward(self, input, adj, seq_start_end=None):
+        """input [N,in], adj dense [N,N] block diagonal (or BlockDiagAdj) -> [N,out]."""
+        from . import _ops
+        from .gat import _layer_plan
+        plan, a = _layer_plan(input, adj, seq_start_end)
+        return _ops.AdjMatmulFn.apply(_ops.MatmulFn.apply(input.float(), self.weight), self.bias, a, plan)
 
 
 class GCN(nn.Module, HipBacked):

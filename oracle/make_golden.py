@@ -35,6 +35,8 @@ from models.baseline.model import VRNN as RefVRNN            # noqa: E402
 from models.dagnet.model import DAGNet as RefDAGNet          # noqa: E402
 from models.dagnet.gat.gat_model import GAT as RefGAT        # noqa: E402
 from models.dagnet.gcn.gcn_model import GCN as RefGCN        # noqa: E402
+from models.dagnet.gat.gat_layers import GraphAttentionLayer as RefGatLayer     # noqa: E402
+from models.dagnet.gcn.gcn_layers import GraphConvolution as RefGcnLayer        # noqa: E402
 from models.utils import adjacency_matrix as ref_adj         # noqa: E402
 from models.utils import utils as ref_utils                  # noqa: E402
 
@@ -329,15 +331,149 @@ def data_case():
     print("data_utils.npz:", len(out), "arrays")
 
 
+def layer_case():
+    """Rows D1 / D3 / E3: the reference's stand-alone layers (gat_layers.py:25-40 with concat True / False,
+    gcn_layers.py:20-26) on block-diagonal adjacencies of types 1 and 2, outputs plus the gradients of sum(out * probe)
+    w.r.t. the input and the layer's parameters; and block_diag_irregular (models/utils/utils.py:290-302) on fp64 [n,n]
+    and [T,n,n] blocks.  -> tests/golden/layers.npz"""
+    sizes, seed = [2, 5, 3, 10], 70
+    n = int(sum(sizes))
+    sse = syn.seq_start_end(sizes)
+    pos = syn.uniform_noise(seed, "layer_pos", (n, 2)) * 10
+    adjs = {1: ref_adj.adjs_distance_sim_pred(1.2, sse, pos), 2: ref_adj.adjs_knn_sim_pred(3, sse, pos)}
+    out = {}
+    specs = (("gat_concat", lambda: RefGatLayer(64, 8, 0.2, concat=True), 64, 8),
+             ("gat_out", lambda: RefGatLayer(32, 64, 0.2, concat=False), 32, 64),
+             ("gat_wide", lambda: RefGatLayer(32, 90, 0.2, concat=False), 32, 90),
+             ("gcn", lambda: RefGcnLayer(64, 8), 64, 8),
+             ("gcn_nobias", lambda: RefGcnLayer(8, 64, bias=False), 8, 64))
+    checks = {}
+    for tag, mk, nin, nout in specs:
+        ref = mk()
+        ref.load_state_dict(syn.random_state_dict(ref, seed))
+        x0 = syn.uniform_noise(seed, "layer_x_" + tag, (n, nin)) * 2 - 1
+        probe = syn.uniform_noise(seed, "layer_probe_" + tag, (n, nout)) * 2 - 1
+        checks[tag] = checksum(x0) + checksum(probe)
+        for at, adj in adjs.items():
+            x = x0.clone().requires_grad_(True)
+            ref.zero_grad()
+            y = ref(x, adj)
+            (y * probe).sum().backward()
+            out[f"{tag}_adj{at}_out"] = y.detach().numpy()
+            out[f"{tag}_adj{at}_dx"] = x.grad.numpy().copy()
+            for k_, p_ in ref.named_parameters():
+                out[f"{tag}_adj{at}_d{k_}"] = p_.grad.numpy().copy()
+    # block_diag_irregular: fp64 blocks in, fp32 out (implicit cast on assignment into torch.zeros)
+    rng = np.random.default_rng(71)
+    b2 = [rng.normal(size=(m, m)) for m in (1, 4, 2, 7)]
+    b3 = [rng.normal(size=(3, m, m)) for m in (2, 5, 3)]
+    for i, b in enumerate(b2):
+        out[f"bd2_in_{i}"] = b
+    for i, b in enumerate(b3):
+        out[f"bd3_in_{i}"] = b
+    o2 = ref_utils.block_diag_irregular([torch.from_numpy(b) for b in b2])
+    o3 = ref_utils.block_diag_irregular([torch.from_numpy(b) for b in b3])
+    assert o2.dtype == torch.float32 and o3.dtype == torch.float32
+    out["bd2_out"], out["bd3_out"] = o2.numpy(), o3.numpy()
+    meta = dict(sizes=sizes, seed=seed, checks=dict(pos=checksum(pos), **checks))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "layers.npz"), **out)
+    print("layers.npz:", len(out), "arrays; bd2", o2.shape, "bd3", o3.shape)
+
+
+MULTI_STEPS = 3
+MULTI_KLD = (0.0, 0.3, 1.0)      # three different KLD warm-up weights (train_bsk.py:377-380 ramps the weight per epoch)
+
+
+def multistep_case(name, kind, args_kw, sizes, obs_len, pred_len, seed, ce_weight=1e-2, lr=1e-3, clip=10.0, data_kind="bsk",
+                   g_cells=(9, 10)):
+    """(f)3: three consecutive optimizer steps of the reference loop body (train_bsk.py:286-291) on three different
+    batches with three KLD weights: Adam's bias correction, moment carry-over and the BatchNorm running statistics over
+    several steps.  Step i uses the batch / noise of seed + 1000 i.  Stored: losses and total norm per step, every
+    gradient per step, and after the last step the state dict, exp_avg and exp_avg_sq."""
+    args = syn.make_args(obs_len=obs_len, pred_len=pred_len, **args_kw)
+    n_max = int(max(sizes))
+    ref = RefVRNN(args) if kind == "vrnn" else RefAVRNN(args) if kind == "avrnn" else RefDAGNet(args, n_max)
+    sd = syn.random_state_dict(ref, seed)
+    ref.load_state_dict(sd)
+    ref.train()
+    opt = torch.optim.Adam(ref.parameters(), lr=lr)
+    out, checks = {}, []
+    for i in range(MULTI_STEPS):
+        s_i = seed + 1000 * i
+        obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = syn.make_batch(sizes, obs_len, pred_len, s_i, kind=data_kind, g_cells=g_cells)
+        N = obs.shape[1]
+        T = obs_len + pred_len if kind == "dagnet" else obs_len
+        eps = syn.uniform_noise(s_i, "eps_train", (T - 1, N, args.z_dim))
+        checks.append(checksum(obs) + checksum(eps))
+        opt.zero_grad()
+        with Injector() as inj:
+            inj.eps = [eps[t] for t in range(T - 1)]
+            if kind == "vrnn":
+                kld, nll, _ = ref(obs_rel)
+                ce = torch.zeros(1)
+                loss = MULTI_KLD[i] * kld + nll
+            elif kind == "avrnn":
+                kld, nll, _ = ref(obs_rel, _ref_obs_adj(args, sse, obs, gt))
+                ce = torch.zeros(1)
+                loss = MULTI_KLD[i] * kld + nll
+            else:
+                adj = _ref_obs_adj(args, sse, obs, gt)
+                traj, rel = torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0)
+                g_ohe = torch.cat((ref_utils.to_goals_one_hot(obs_goals, args.g_dim), ref_utils.to_goals_one_hot(gt_goals, args.g_dim)), 0)
+                kld, nll, ce, _ = ref(traj, rel, g_ohe, sse, adj)
+                loss = MULTI_KLD[i] * kld + nll + ce * ce_weight
+            assert not inj.eps
+        loss.backward()
+        for k_, v in (("kld", kld), ("nll", nll), ("ce", ce), ("loss", loss)):
+            out[f"step{i}/{k_}"] = v.detach().numpy().copy()
+        for k_, p_ in ref.named_parameters():
+            out[f"step{i}/grad/{k_}"] = (p_.grad if p_.grad is not None else torch.zeros_like(p_)).numpy().copy()
+        out[f"step{i}/total_norm"] = np.float32(torch.nn.utils.clip_grad_norm_(ref.parameters(), clip))
+        opt.step()
+    for k_, v in ref.state_dict().items():
+        out["after/" + k_] = v.detach().numpy().copy()
+    names = [k_ for k_, _ in ref.named_parameters()]
+    st = opt.state_dict()["state"]
+    for i, k_ in enumerate(names):
+        out["exp_avg/" + k_] = st[i]["exp_avg"].numpy().copy()
+        out["exp_avg_sq/" + k_] = st[i]["exp_avg_sq"].numpy().copy()
+        assert int(st[i]["step"]) == MULTI_STEPS
+    meta = dict(name=name, kind=kind, args=args_kw, sizes=[int(s_) for s_ in sizes], obs_len=obs_len, pred_len=pred_len, seed=seed,
+                data_kind=data_kind, g_cells=list(g_cells), n_max_agents=n_max, kld_weights=list(MULTI_KLD), ce_weight=ce_weight, lr=lr,
+                clip=clip, steps=MULTI_STEPS, checks=dict(steps=checks,
+                                                         weights=float(sum(checksum(v) for v in sd.values() if v.dtype.is_floating_point))))
+    out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: {MULTI_STEPS} steps, losses", [float(out[f'step{i}/loss']) for i in range(MULTI_STEPS)],
+          "norms", [float(out[f'step{i}/total_norm']) for i in range(MULTI_STEPS)])
+
+
+def multistep_cases():
+    # lr = 2e-4: parameters whose gradient is pure rounding noise (the out head's attention vector, a bias in front of a
+    # train-mode BatchNorm) still move by +-lr per Adam step, in a direction the noise decides; a small lr keeps the effect
+    # of that wandering on the later steps' gradients below the comparison tolerance
+    multistep_case("multistep_dagnet_tiny_gat", "dagnet", dict(TINY, n_layers=2, graph_model="gat", adjacency_type=1), [2, 5, 3], 4, 5, 163,
+                   g_cells=(3, 4), data_kind="sdd", lr=2e-4)
+    multistep_case("multistep_avrnn_tiny_gcn", "avrnn", dict(TINY, n_layers=2, graph_model="gcn", adjacency_type=2, top_k_neigh=3), [2, 5, 3], 4, 5, 162,
+                   lr=2e-4)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         return train_cases()
+    if len(sys.argv) > 1 and sys.argv[1] == "layers":
+        return layer_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "train3":
+        return multistep_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "data":
         return data_case()
     data_case()
     state_dict_layouts()
     train_cases()
+    layer_case()
+    multistep_cases()
     # --- tiny dims, ragged scenes, every graph x adjacency combination
     for L in (1, 2):
         build_case(f"vrnn_tiny_L{L}", "vrnn", dict(TINY, n_layers=L), [2, 5, 3], 4, 5, 10 + L, 2)

@@ -88,3 +88,85 @@ def test_train_mode_forward_without_grad_uses_batch_statistics():
     assert not kld.requires_grad
     np.testing.assert_allclose(kld.cpu().numpy(), gold["kld"], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(nll.cpu().numpy(), gold["nll"], rtol=1e-4, atol=1e-5)
+
+
+# ---- three consecutive optimizer steps ((f)3) ------------------------------------------------------------------------
+def _multistep_batch(meta, i):
+    from dagnet_amd.adjacency_matrix import compute_adjs, compute_adjs_distsim, compute_adjs_knnsim
+    from tests.test_oracle_train import multistep_inputs
+    batch, eps = multistep_inputs(meta, i)
+    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = [t.to(DEV) for t in batch]
+    args = cases.syn.make_args(obs_len=meta["obs_len"], pred_len=meta["pred_len"], **meta["args"])
+    if meta["kind"] == "vrnn":
+        return (obs_rel,), eps.to(DEV)
+    adj = (compute_adjs(args, sse, device=DEV) if args.adjacency_type == 0 else
+           compute_adjs_distsim(args, sse, obs, gt) if args.adjacency_type == 1 else compute_adjs_knnsim(args, sse, obs, gt))
+    if meta["kind"] == "avrnn":
+        return (obs_rel, adj, sse), eps.to(DEV)
+    goals = torch.cat((obs_goals, gt_goals), 0).to(torch.int32)
+    return (torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0), goals, sse, adj), eps.to(DEV)
+
+
+def _run_step(meta, model, opt, i):
+    """training.train_step on the batch of step i -> the per-step record check_multistep wants.  The optimizer clips the
+    gradients in place, so the raw gradients are p.grad / coef."""
+    from dagnet_amd import training
+    batch, eps = _multistep_batch(meta, i)
+    r = training.train_step(model, opt, batch, kld_weight=meta["kld_weights"][i], ce_weight=meta["ce_weight"], eps=eps)
+    tn = float(opt.total_norm().cpu())
+    coef = min(1.0, meta["clip"] / (tn + 1e-6))
+    grads = {k: (p.grad.detach().cpu() / coef if p.grad is not None else torch.zeros_like(p).cpu()) for k, p in model.named_parameters()}
+    return dict(kld=r["kld"].cpu(), nll=r["nll"].cpu(), ce=r["ce"].cpu(), loss=r["loss"].cpu(), grads=grads, total_norm=tn)
+
+
+def _final(model, opt):
+    names = [k for k, _ in model.named_parameters()]
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    return dict(params={k: sd[k] for k in names}, buffers=sd, m={k: m.cpu() for k, m in zip(names, opt.m)},
+                v={k: v.cpu() for k, v in zip(names, opt.v)})
+
+
+@pytest.mark.parametrize("arena", [False, True])
+@pytest.mark.parametrize("name", ["multistep_dagnet_tiny_gat", "multistep_avrnn_tiny_gcn"])
+def test_three_training_steps_match_reference(name, arena):
+    """Adam bias correction, moment carry-over and BatchNorm running statistics over three reference steps
+    (train_bsk.py:286-291 x 3, different batches and KLD weights)."""
+    from dagnet_amd import _ops
+    from dagnet_amd.training import attach_grad_arena
+    from tests.test_oracle_train import check_multistep
+    meta, gold = cases.load_golden(name)
+    _, model, _ = cases.build_model(meta)
+    model = model.to(DEV)
+    opt = _ops.ClipAdam(list(model.parameters()), lr=meta["lr"], clip=meta["clip"])
+    if arena:
+        attach_grad_arena(model, opt)
+    steps = [_run_step(meta, model, opt, i) for i in range(meta["steps"])]
+    assert opt.step_count == meta["steps"]
+    check_multistep(steps, _final(model, opt), gold, meta)
+
+
+@pytest.mark.parametrize("name", ["multistep_dagnet_tiny_gat", "multistep_avrnn_tiny_gcn"])
+def test_checkpoint_resume_reproduces_the_third_step(name, tmp_path):
+    """two steps -> loop.save_checkpoint -> a fresh model / optimizer / scheduler via loop.load_checkpoint -> the third step:
+    parameters, Adam moments and BatchNorm buffers must equal the reference's after its third step (train_bsk.py:80-93,
+    :340-366)."""
+    import dagnet_amd
+    from dagnet_amd import _ops, loop
+    from tests.test_oracle_train import check_multistep
+    meta, gold = cases.load_golden(name)
+    args, model, _ = cases.build_model(meta)
+    model = model.to(DEV)
+    opt = _ops.ClipAdam(list(model.parameters()), lr=meta["lr"], clip=meta["clip"])
+    sched = loop.PlateauScheduler(opt)
+    steps = [_run_step(meta, model, opt, i) for i in range(2)]
+    fn = tmp_path / "checkpoint_epoch_2.pth"
+    loop.save_checkpoint(fn, args, 2, model, opt, sched, 1.0, [], [], [], [])
+    fresh = (dagnet_amd.DAGNet(args, meta["n_max_agents"]) if meta["kind"] == "dagnet" else dagnet_amd.AVRNN(args)).to(DEV)
+    opt2 = _ops.ClipAdam(list(fresh.parameters()), lr=123.0, clip=meta["clip"])
+    ck = loop.load_checkpoint(fn, fresh, opt2, loop.PlateauScheduler(opt2))
+    assert ck["epoch"] == 2 and opt2.step_count == 2 and opt2.lr == pytest.approx(meta["lr"])
+    # the reference's own optimizer accepts the file's optimizer state
+    ref_opt = torch.optim.Adam([torch.nn.Parameter(torch.zeros_like(p, device="cpu")) for p in fresh.parameters()], lr=1.0)
+    ref_opt.load_state_dict(ck["optimizer_state_dict"])
+    steps.append(_run_step(meta, fresh, opt2, 2))
+    check_multistep(steps, _final(fresh, opt2), gold, meta)

@@ -5,8 +5,13 @@
 
 Metric (BASELINE.json): sampled trajectories / second = scenes x agents x K / t_rollout, inputs
 (h after the observed steps, last positions, last goals, GT future) already resident in HBM.
-N > 1: one process per GPU (torch.distributed / RCCL), scenes sharded, weak scaling (per-GPU work
-fixed), one all-reduce of (ade_sum, fde_sum, n_agents) per step; value = all ranks' trajectories / max time.
+N > 1: one process per GPU (torch.distributed / RCCL), scenes sharded, one all-reduce of (ade_sum, fde_sum, n_agents) per
+step; value = all ranks' trajectories / max time over ranks.  Either the driver starts the ranks (torch.distributed.run:
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when --gpus N > 1 is given WITHOUT WORLD_SIZE, this
+script starts N child processes itself - before anything in the parent touches the GPU; the parent only waits and relays
+rank 0's JSON line.  Workloads are weak scaling (fixed scenes per rank) except dagnet_bsk_1Mx20 (BASELINE configs[4]:
+1 048 576 scenes in total, sharded over the ranks, walked in chunks of 4096 scenes: strong scaling).
+--rehearse runs the launcher, the process group (gloo, CPU) and the reductions with no GPU work (a CPU test uses it).
 """
 from __future__ import annotations
 
@@ -39,6 +44,12 @@ def pmc_traffic(workload, kernel):
             ks = json.load(open(path)).get(workload, {}).get("kernels", {})
         except (OSError, ValueError):
             continue
+        # a section that lists a rollout kernel of ANOTHER dispatch path was recorded before the path changed: stale
+        family = {"rollout_v2_kernel": ("rollout_v2_kernel",), "gemm_nt_kernel": ("gemm_nt_kernel", "rollout_v2_kernel", "wide::"),
+                  "dagnet_rollout_big_kernel": ("dagnet_rollout_big_kernel",), "dagnet_rollout_kernel": ("dagnet_rollout_kernel",)}
+        ok = family.get(kernel.split(" ")[0], ())
+        if not ks or any(not any(f in name for f in ok) for name in ks):
+            continue
         hits = [float(v["traffic_bytes_per_launch"]) for name, v in ks.items()
                 if kernel.split(" ")[0] + "<" in name and "traffic_bytes_per_launch" in v]
         if hits:
@@ -53,6 +64,13 @@ WORKLOADS = {
     # configs[3]: DAG-Net SDD-shaped: obs 8 / pred 12, ragged scenes (2..32 agents, mean 6), g_dim = 32 x 30 = 960
     "dagnet_sdd_1024x20": dict(kind="dagnet", scenes=1024, agents=0, K=20, obs=8, pred=12, args=dict(n_layers=2, g_dim=960),
                                data="sdd", g_cells=(32, 30)),
+    # configs[3] at the size SURVEY 8(d) states (cfg4: S = 4096 ragged scenes, K = 20)
+    "dagnet_sdd_4096x20": dict(kind="dagnet", scenes=4096, agents=0, K=20, obs=8, pred=12, args=dict(n_layers=2, g_dim=960),
+                               data="sdd", g_cells=(32, 30)),
+    # configs[4], evaluation leg: 1 048 576 scenes x 20 samples in total, sharded over the ranks (strong scaling), every rank
+    # walks its share in chunks of 4096 scenes (one sample_k launch + one metric launch per chunk, sums added on the device)
+    "dagnet_bsk_1Mx20": dict(kind="dagnet", scenes=0, total_scenes=1 << 20, chunk=4096, agents=10, K=20, obs=10, pred=40,
+                             args=dict(n_layers=2)),
     # configs[0] shape on the GPU: VRNN baseline
     "vrnn_bsk_4096x20": dict(kind="vrnn", scenes=4096, agents=10, K=20, obs=10, pred=40, args=dict(n_layers=2)),
     # configs[4], training leg (row T): one optimizer step of DAG-Net on a chunk of scenes, full 50-step sequence
@@ -138,6 +156,38 @@ def cpu_baseline(wl, budget_s=20.0):
     dt = time.perf_counter() - t0
     return dict(value=N * done / dt, unit="trajectories/s", cores=cores, kind="port",
                 sample=f"{scenes} scenes x {n} agents x {done} samples x {T} steps, dense-graph oracle, torch CPU fp32")
+
+
+def cpu_baseline_stock(wl, kind=None, scenes=32, budget_s=10.0):
+    """The reference's sample() call pattern on stock torch.nn layers (oracle/stock_torch.py: dense [N,N,2F] attention over
+    the whole flattened batch, per-scene scipy adjacency, nn.GRU per step) - what a user of the reference pays on the host
+    cores today.  32 scenes = the reference's eval batch (models/dagnet/evaluate_bsk.py:32).  Pinned against the reference's
+    own outputs by tests/test_stock_baseline.py."""
+    from oracle.stock_torch import StockRollout
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    kind = kind or wl["kind"]
+    n, T = wl["agents"] or 6, wl["pred"]
+    a = syn.make_args(obs_len=wl["obs"], pred_len=T, **{k: v for k, v in wl["args"].items() if kind == "dagnet" or k != "g_dim"})
+    n_max = wl["agents"] or 32
+    m = StockRollout(kind, a, n_max)
+    ours = {"dagnet": lambda: dagnet_amd.DAGNet(a, n_max), "avrnn": lambda: dagnet_amd.AVRNN(a), "vrnn": lambda: dagnet_amd.VRNN(a)}[kind]()
+    m.load_state_dict(syn.random_state_dict(ours, 128))
+    m.eval()
+    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = syn.make_batch([n] * scenes, wl["obs"], T, 1, kind=wl.get("data", "bsk"),
+                                                                        g_cells=wl.get("g_cells", (9, 10)))
+    N = obs.shape[1]
+    h = syn.uniform_noise(1, "h0", (a.n_layers, N, a.rnn_dim)) - 0.5
+    g0 = torch.nn.functional.one_hot(obs_goals[-1].long(), a.g_dim).float() if kind == "dagnet" else None
+    torch.manual_seed(0)
+    t0 = time.perf_counter()
+    done = 0
+    while done < wl["K"] and (done == 0 or time.perf_counter() - t0 < budget_s):
+        m.sample(T, h.clone(), obs[-1] if kind != "vrnn" else None, g0, sse)
+        done += 1
+    dt = time.perf_counter() - t0
+    return dict(value=N * done / dt, unit="trajectories/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{kind}: {scenes} scenes x {n} agents x {done} samples x {T} steps, stock torch.nn layers with the reference's dense "
+                       "[N,N,2F] graph attention and per-scene scipy adjacency (oracle/stock_torch.py), torch CPU fp32")
 
 
 def train_flops_per_row_step(a, n, d_dim):
@@ -246,6 +296,81 @@ def cpu_train_baseline(wl):
                 sample=f"one training step on {scenes} scenes x {n} agents x {traj.shape[0]} steps, dense-graph oracle, torch CPU autograd")
 
 
+def device_batch(S, n, obs_len, pred_len, seed, dev):
+    """Basketball-shaped batch generated ON the device (the 1M-scene workload: numpy would spend minutes on it): same
+    distributions and tuple layout as synthetic.make_batch (half court 45 x 50 ft, N(0, 0.5 ft) steps, 9 x 10 goal grid)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    N, T = S * n, obs_len + pred_len
+    start = torch.rand((N, 2), generator=g, device=dev) * torch.tensor([45.0, 50.0], device=dev)
+    steps = torch.randn((T, N, 2), generator=g, device=dev) * 0.5
+    steps[0] = 0.0
+    traj = start[None] + torch.cumsum(steps, 0)
+    rel = torch.zeros_like(traj)
+    rel[1:] = traj[1:] - traj[:-1]
+    goals = (torch.clamp((traj[..., 0] // 5).long(), 0, 8) * 10 + torch.clamp((traj[..., 1] // 5).long(), 0, 9)).float()
+    st = torch.arange(0, N, n, dtype=torch.int64)
+    return (traj[:obs_len].contiguous(), traj[obs_len:].contiguous(), rel[:obs_len].contiguous(), rel[obs_len:].contiguous(),
+            goals[:obs_len].contiguous(), goals[obs_len:].contiguous(), torch.stack((st, st + n), 1))
+
+
+def self_launch(opt, argv):
+    """--gpus N > 1 without a launcher: start N ranks of this script (one per GPU) and relay rank 0's output.  Runs BEFORE
+    anything touches the GPU in this process, which only waits (never exec from a process that initialised the GPU)."""
+    import socket
+    import subprocess
+    if not opt.rehearse and torch.cuda.device_count() < opt.gpus:        # device_count() does not initialise the GPU
+        raise SystemExit(f"--gpus {opt.gpus} but only {torch.cuda.device_count()} visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(opt.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(opt.gpus), LOCAL_WORLD_SIZE=str(opt.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0's stdout is relayed (its JSON line and nothing else reaches our stdout); the other ranks' goes to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    for ln in procs[0].stdout:
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+        sys.stdout.flush()
+    rc = 0
+    for pr in procs:
+        rc = pr.wait() or rc
+        if rc:                                                           # a rank died: do not leave the others hanging
+            for other in procs:
+                if other.poll() is None:
+                    other.kill()
+    raise SystemExit(rc)
+
+
+def rehearse(opt, wl, rank, world):
+    """Host logic of an N-rank run without a GPU: process group (gloo), scene sharding, the step's 3-double all-reduce, the
+    max-over-ranks timing, rank 0's JSON line.  The per-rank numbers are made up (rows of the shard); nothing is measured."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    S = wl["scenes"] or wl["total_scenes"] // world
+    rows = S * (wl["agents"] or 6)
+    t0 = time.perf_counter()
+    for _ in range(opt.steps):
+        tot = torch.tensor([1.0 * rows, 2.0 * rows, float(rows)], dtype=torch.float64)
+        dist.all_reduce(tot)
+    dist.barrier()
+    tmax = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    traj = torch.tensor([float(rows * wl["K"])], dtype=torch.float64)
+    dist.all_reduce(traj)
+    if rank == 0:
+        print(json.dumps({"metric": "rehearsal (no GPU work, nothing measured)", "rehearsal": True, "value": None,
+                          "n_gpus": dist.get_world_size(), "steps": opt.steps, "warmup": opt.warmup,
+                          "scaling": "strong" if wl.get("total_scenes") else "weak",
+                          "config": {"workload": opt.workload, "scenes_per_gpu": S, "rows_all_ranks": float(tot[2]),
+                                     "trajectories_per_step": float(traj)}}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,14 +379,19 @@ def main():
     ap.add_argument("--workload", default="dagnet_bsk_4096x20", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="training workloads: issue every launch from the host instead of replaying a hipGraph")
+    ap.add_argument("--rehearse", action="store_true", help="launcher + process group + reductions on the CPU (gloo), no GPU work")
     opt = ap.parse_args()
     wl = WORKLOADS[opt.workload]
 
+    if opt.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(opt, sys.argv[1:])
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if opt.gpus != world and world > 1:
+    if opt.gpus != world:
         raise SystemExit(f"--gpus {opt.gpus} but WORLD_SIZE={world}")
+    if opt.rehearse:
+        return rehearse(opt, wl, rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -269,6 +399,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        world_seen = dist.get_world_size()
+    else:
+        world_seen = 1
 
     if wl.get("train"):
         bench_train(opt, wl, rank, world, dev, dist)
@@ -276,52 +409,80 @@ def main():
             dist.destroy_process_group()
         return
     a, model = build(wl, dev)
-    S, K, T = wl["scenes"], wl["K"], wl["pred"]
-    sizes = scene_sizes(wl, seed=rank)
+    K, T = wl["K"], wl["pred"]
+    strong = bool(wl.get("total_scenes"))
+    S = wl["total_scenes"] // world if strong else wl["scenes"]
+    chunk = wl.get("chunk", S)
+    from dagnet_amd.evaluate import _obs_adjacency, best_of_k_chunked
+    if strong:
+        sizes = [wl["agents"]] * S
+        batch = device_batch(S, wl["agents"], wl["obs"], T, 1000 + rank, dev)
+    else:
+        sizes = scene_sizes(wl, seed=rank)      # weak scaling: every rank owns S scenes of its own (seeded by rank)
+        batch = [t.to(dev) for t in syn.make_batch(sizes, wl["obs"], T, 1000 + rank, kind=wl.get("data", "bsk"),
+                                                   g_cells=wl.get("g_cells", (9, 10)))]
     n_rows = int(sum(sizes))
     n = n_rows / S                      # agents per scene (mean, for ragged workloads)
-    # weak scaling: every rank owns S scenes of its own (seeded by rank)
-    batch = [t.to(dev) for t in syn.make_batch(sizes, wl["obs"], T, 1000 + rank, kind=wl.get("data", "bsk"),
-                                               g_cells=wl.get("g_cells", (9, 10)))]
     obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = batch
-    from dagnet_amd.evaluate import _obs_adjacency
     goals = obs_goals.to(torch.int32)
+    sp = scene_ptr_from_sse(sse)
+
     # observed steps (outside the timed region; reported separately: second call, weights packed and plan built)
-    adj_obs = _obs_adjacency(a, sse, obs, gt) if wl["kind"] != "vrnn" else None
+    def fwd_chunk(c0, c1):
+        a0, a1 = int(sp[c0]), int(sp[c1])
+        o, r_, g_, gt_c = obs[:, a0:a1], obs_rel[:, a0:a1], goals[:, a0:a1], gt[:, a0:a1]
+        sse_c = sse[c0:c1] - a0
+        adj_obs = _obs_adjacency(a, sse_c, o, gt_c) if wl["kind"] != "vrnn" else None
+        if wl["kind"] == "dagnet":
+            return model(o.contiguous(), r_.contiguous(), g_.contiguous(), sse_c, adj_obs, seed=1 + c0)[3]
+        if wl["kind"] == "avrnn":
+            return model(r_.contiguous(), adj_obs, seq_start_end=sse_c, seed=1 + c0)[2]
+        return model(r_.contiguous(), seed=1 + c0)[2]
 
     def fwd():
-        if wl["kind"] == "dagnet":
-            return model(obs, obs_rel, goals, sse, adj_obs, seed=1)[3]
-        if wl["kind"] == "avrnn":
-            return model(obs_rel, adj_obs, seq_start_end=sse, seed=1)[2]
-        return model(obs_rel, seed=1)[2]
+        return torch.cat([fwd_chunk(c0, min(S, c0 + chunk)) for c0 in range(0, S, chunk)], 1)
     h = fwd()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     h = fwd()
     torch.cuda.synchronize()
     fwd_ms = (time.perf_counter() - t0) * 1e3
-    sp = scene_ptr_from_sse(sse)
-    metric_plan = _capi.HipPlan(None, sp, 1, device=dev)
     x0, g0 = obs[-1].contiguous(), goals[-1].contiguous()
+    n_chunks = (S + chunk - 1) // chunk
+    n_dev = torch.tensor([float(n_rows)], dtype=torch.float64, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(opt.steps)]
+    plan_sp = sp[:chunk + 1] if n_chunks > 1 else sp
 
-    def step(i, timed):
-        if timed:
-            ev[i][0].record()
-        if wl["kind"] == "dagnet":
-            s = model.sample_k(K, T, h, x0, g0, sse, seed=i + 1)
-        elif wl["kind"] == "avrnn":
-            s = model.sample_k(K, T, h, x0, sse, seed=i + 1)
-        else:
-            s = model.sample_k(K, T, h, seed=i + 1)
-        if timed:
-            ev[i][1].record()
-        r = _capi.best_of_k(metric_plan, s, x0, gt)
-        tot = torch.cat([r["sums"], torch.tensor([float(n_rows)], dtype=torch.float64, device=dev)])
-        if dist is not None:
-            dist.all_reduce(tot)
-        return tot
+    if n_chunks > 1:
+        def step(i, timed):
+            # chunked walk (configs[4]): events bracket the whole walk; kernel_ms below is per chunk launch
+            if timed:
+                ev[i][0].record()
+            tot = best_of_k_chunked(model, a, K, h, x0, g0, gt, sse, chunk, seed=(i + 1) * 100003)
+            if timed:
+                ev[i][1].record()
+            if dist is not None:
+                dist.all_reduce(tot)
+            return tot
+    else:
+        metric_plan = _capi.HipPlan(None, sp, 1, device=dev)
+
+        def step(i, timed):
+            if timed:
+                ev[i][0].record()
+            if wl["kind"] == "dagnet":
+                s = model.sample_k(K, T, h, x0, g0, sse, seed=i + 1)
+            elif wl["kind"] == "avrnn":
+                s = model.sample_k(K, T, h, x0, sse, seed=i + 1)
+            else:
+                s = model.sample_k(K, T, h, seed=i + 1)
+            if timed:
+                ev[i][1].record()
+            r = _capi.best_of_k(metric_plan, s, x0, gt)
+            tot = torch.cat([r["sums"], n_dev])
+            if dist is not None:
+                dist.all_reduce(tot)
+            return tot
 
     for i in range(opt.warmup):
         step(i, False)
@@ -351,25 +512,47 @@ def main():
         d_dim = 2 * (wl["agents"] or 32)
         launch_flop = float(sum(flops_per_row_step(wl["kind"], a, ns, d_dim) * ns for ns in sizes)) * T * K   # this rank's rows
         fl = launch_flop / (n_rows * K)                                # FLOP per sampled trajectory (mean)
+        if n_chunks > 1:
+            # the events bracket n_chunks (sample + metric) launch pairs; the metric kernels are ~0.1 % of it
+            kernel_ms /= n_chunks
+            launch_flop /= n_chunks
         achieved = launch_flop / (kernel_ms * 1e-3) / 1e12
-        info = model.hip_plan(dev, sp, K).info()
+        info = model.hip_plan(dev, np.ascontiguousarray(plan_sp - plan_sp[0]), K).info()
         line = {
             "metric": "sampled trajectories/sec (best-of-20 rollout)", "value": value, "unit": "trajectories/s",
-            "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "n_gpus": world_seen, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": opt.workload, "model": wl["kind"], "scenes_per_gpu": S, "agents_per_scene": n,
                        "samples": K, "obs_len": wl["obs"], "pred_len": T, "rows_per_gpu": n_rows * K,
+                       "chunks_per_step": n_chunks, "scenes_per_chunk": chunk,
                        "tile_rows": info["tile_rows"], "tiles": info["n_tiles"], "lds_bytes": info["lds_bytes"],
-                       "parallelism": f"scenes sharded x{world}, 1 all-reduce of 3 doubles per step"},
+                       "parallelism": f"scenes sharded x{world_seen}, 1 all-reduce of 3 doubles per step"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": pmc_traffic(opt.workload, info["sample_kernel"]),
+                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
+                         "traffic": pmc_traffic("dagnet_bsk_4096x20" if strong else opt.workload, info["sample_kernel"]),
                          "kernel": info["sample_kernel"], "kernel_ms": kernel_ms,
                          "flop_per_trajectory": fl},
             "forward_obs_ms": fwd_ms,
             "ade": float(tot[0] / (tot[2] * T)), "fde": float(tot[1] / tot[2]),
         }
-        if not opt.no_cpu_baseline and world == 1:         # the CPU leg runs on rank 0 of the single-GPU run only
-            line["cpu_baseline"] = cpu_baseline(wl)
+        if n_chunks == 1:
+            # the reference's evaluation loop AS WRITTEN (models/dagnet/evaluate_bsk.py:113-114): K separate sample() calls
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for k in range(K):
+                if wl["kind"] == "dagnet":
+                    model.sample(T, h, x0, g0, sse, seed=1000 + k)
+                elif wl["kind"] == "avrnn":
+                    model.sample(T, h, x0, sse, seed=1000 + k)
+                else:
+                    model.sample(T, h, seed=1000 + k)
+            torch.cuda.synchronize()
+            line["reference_loop_ms"] = (time.perf_counter() - t0) * 1e3
+        if not opt.no_cpu_baseline and world == 1:         # the CPU legs run on rank 0 of the single-GPU run only
+            line["cpu_baseline"] = cpu_baseline(wl, budget_s=12.0)
+            line["cpu_baseline_torch_nn"] = cpu_baseline_stock(wl, budget_s=8.0)
+            # BASELINE configs[0]: VRNN baseline, best-of-20 on the CPU reference path (32 scenes x 10 agents, obs 10 / pred 40)
+            line["cpu_baseline_vrnn"] = cpu_baseline_stock(WORKLOADS["vrnn_bsk_4096x20"], budget_s=6.0)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()

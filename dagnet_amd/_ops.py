@@ -75,13 +75,18 @@ def _lib():
 # plumbing
 # ---------------------------------------------------------------------------------------------
 _scratch: Dict[torch.device, torch.Tensor] = {}
+_scratch_retired = []        # outgrown buffers stay alive: a captured hipGraph may have their address baked into its nodes
 
 
 def _ws(device, nfloats: int) -> torch.Tensor:
-    """Per-device scratch (split-reduction partials).  Kernels of one stream run in order, so one buffer is enough."""
+    """Per-device scratch (split-reduction partials).  Kernels of one stream run in order, so one buffer is enough.
+    A buffer that is outgrown is retired, never freed (training.GraphedForwardBackward replays launches that hold its
+    pointer; handing the memory back to the caching allocator would let a replay scribble over another tensor)."""
     t = _scratch.get(device)
     if t is None or t.numel() < nfloats:
-        t = torch.empty(max(int(nfloats), 1 << 16), dtype=torch.float32, device=device)
+        if t is not None:
+            _scratch_retired.append(t)
+        t = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
         _scratch[device] = t
     return t
 
@@ -182,6 +187,13 @@ class DeferredGrads:
         if not self.pending:
             self.pending = True
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
+
+    def reset(self):
+        """Forget an accumulation that never finished (a backward pass that raised drops the engine callback): without
+        this the next backward would neither queue finish() nor overwrite the stale partial sums."""
+        self.pending = False
+        for slot in self.slots.values():
+            slot["first"], slot["dirty"] = True, False
 
     def finish(self):
         lib = _lib()
@@ -642,6 +654,8 @@ class ClipAdam:
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
 
     def zero_grad(self):
+        for d in {id(d): d for d in (getattr(p, "_hip_defer", None) for p in self.params) if d is not None}.values():
+            d.reset()                           # a backward pass that raised must not poison this step
         arena = getattr(self, "arena", None)
         if arena is not None and all(getattr(p, "_hip_sink", False) and p.grad is not None for p in self.params):
             arena.zero_()                       # the parameters' .grad are views of one flat buffer

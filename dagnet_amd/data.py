@@ -128,8 +128,12 @@ class SceneBatcher:
         batch is one ``index_select`` of rows per field on the device.
 
     Every batch is ``fields... + (seq_start_end [S,2] int64,)`` with rows renumbered from 0, i.e. exactly what
-    ``seq_collate`` returns for those scenes.  ``rank`` / ``world`` split the scenes of every batch for data-parallel runs
-    (contiguous shares, the same batch boundaries on every rank)."""
+    ``seq_collate`` returns for those scenes.  ``rank`` / ``world`` split the scenes of every batch for data-parallel runs:
+    the same batch boundaries on every rank, scene i of the batch goes to the rank with ``lo <= i < hi``,
+    ``lo = len * rank // world`` (even shares, sizes differ by at most one).  Every rank yields EVERY batch, so the ranks
+    stay in lock-step for the collectives of the step; a rank whose share is empty (a short last batch) gets a batch with
+    zero rows and an empty ``seq_start_end`` and must still take part in them (``loop.train`` does).  ``global_rows`` /
+    ``global_scenes`` describe the whole batch that was just yielded (all ranks), e.g. for ``row_fraction``."""
 
     def __init__(self, fields, scene_ptr, batch_size, shuffle=False, device=None, generator=None, rank=0, world=1):
         self.ptr = np.asarray(scene_ptr, dtype=np.int64)
@@ -137,6 +141,9 @@ class SceneBatcher:
         self.batch_size, self.shuffle, self.gen = int(batch_size), bool(shuffle), generator
         self.rank, self.world = int(rank), int(world)
         self.dataset = self                      # len(loader.dataset) as the reference's epoch functions use it
+        if not (0 <= self.rank < self.world):
+            raise ValueError(f"rank {rank} outside world {world}")
+        self.global_rows = self.global_scenes = 0
 
     def __len__(self):                           # scenes (as len(dataset)); number of batches: n_batches()
         return len(self.ptr) - 1
@@ -153,10 +160,12 @@ class SceneBatcher:
         dev = self.fields[0].device
         for b0 in range(0, S, self.batch_size):
             scenes = order[b0:b0 + self.batch_size]
+            self.global_scenes = len(scenes)
+            self.global_rows = int(np.sum(self.ptr[scenes + 1] - self.ptr[scenes]))
             if self.world > 1:
-                share = (len(scenes) + self.world - 1) // self.world
-                scenes = scenes[self.rank * share:(self.rank + 1) * share]
-                if len(scenes) == 0:
+                scenes = scenes[len(scenes) * self.rank // self.world:len(scenes) * (self.rank + 1) // self.world]
+                if len(scenes) == 0:             # stay in lock-step: an empty share is still a batch
+                    yield tuple([f[:, 0:0] for f in self.fields] + [torch.zeros((0, 2), dtype=torch.int64)])
                     continue
             sizes = self.ptr[scenes + 1] - self.ptr[scenes]
             ends = np.cumsum(sizes)

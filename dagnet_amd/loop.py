@@ -41,9 +41,36 @@ def _split(data, kind):
     return obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, data[-1]
 
 
+def sub_seed(seed, batch_index, phase):
+    """Philox seed of one call site: the counter of csrc/rng.h is (row, t, j, stream) only, so the teacher-forced pass
+    (phase 0) and the rollout (phase 1) of one batch, and the batches of one epoch, get seeds of their own -
+    2 (seed + batch_index) + phase - instead of drawing the same numbers at the same (row, t).  None stays None."""
+    return None if seed is None else 2 * (int(seed) + int(batch_index)) + int(phase)
+
+
+def _dist_on():
+    return torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1
+
+
+def _row_fraction(loader, n_local, dev):
+    """N_local / N_global of the batch in flight (1.0 in a single process).  A SceneBatcher knows the whole batch on every
+    rank; any other loader costs one all-reduce of the row count."""
+    if not _dist_on():
+        return 1.0
+    n_global = getattr(loader, "global_rows", 0)
+    if not n_global:
+        t = torch.tensor([float(n_local)], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t)
+        n_global = float(t.item())
+    return float(n_local) / float(n_global) if n_global else 0.0
+
+
 def _eval_pass(args, epch, loader, model, warmup, seed=None):
     """validate() / test() of the reference minus the side effects: per batch the teacher-forced pass over the observed
-    steps, the loss, ONE sample() from the last h, 'sum'-mode ADE / FDE.  -> dict of python floats."""
+    steps, the loss, ONE sample() from the last h, 'sum'-mode ADE / FDE.  -> dict of python floats.
+    Data parallel: KLD / NLL of a batch are means over its rows, so a rank weighs them by its share of the batch's rows;
+    the seven partial sums are all-reduced once per pass, so every rank returns the same numbers (and steps its plateau
+    scheduler identically)."""
     kind = _kind(model)
     dev = next(model.parameters()).device
     acc = torch.zeros(7, dtype=torch.float64, device=dev)       # loss, kld, nll, ce, ade, fde, total_traj
@@ -53,30 +80,34 @@ def _eval_pass(args, epch, loader, model, warmup, seed=None):
     with torch.no_grad():
         for data in loader:
             obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = _split([t.to(dev) for t in data], kind)
-            s = None if seed is None else seed + n_batches
+            s_f, s_s = sub_seed(seed, n_batches, 0), sub_seed(seed, n_batches, 1)
             n_batches += 1
+            frac = _row_fraction(loader, obs.shape[1], dev)
+            if obs.shape[1] == 0:                     # this rank's share of a short batch is empty
+                continue
             if kind == "dagnet":
                 adj = _obs_adjacency(args, sse, obs, gt)
                 goals = obs_goals.to(torch.int32)
-                kld, nll, ce, h = model(obs, obs_rel, goals, sse, adj, seed=s)
-                loss = nll + w * kld + ce * args.CE_weight
-                samples_rel = model.sample(args.pred_len, h, obs[-1], goals[-1], sse, seed=s)
+                kld, nll, ce, h = model(obs, obs_rel, goals, sse, adj, seed=s_f)
+                samples_rel = model.sample(args.pred_len, h, obs[-1], goals[-1], sse, seed=s_s)
             elif kind == "avrnn":
                 adj = _obs_adjacency(args, sse, obs, gt)
-                kld, nll, h = model(obs_rel, adj, seq_start_end=sse, seed=s)
+                kld, nll, h = model(obs_rel, adj, seq_start_end=sse, seed=s_f)
                 ce = torch.zeros_like(kld)
-                loss = nll + w * kld
-                samples_rel = model.sample(args.pred_len, h, obs[-1], sse, seed=s)
+                samples_rel = model.sample(args.pred_len, h, obs[-1], sse, seed=s_s)
             else:
-                kld, nll, h = model(obs_rel, seed=s)
+                kld, nll, h = model(obs_rel, seed=s_f)
                 ce = torch.zeros_like(kld)
-                loss = nll + w * kld
-                samples_rel = model.sample(args.pred_len, h, seed=s)
+                samples_rel = model.sample(args.pred_len, h, seed=s_s)
+            kld, nll = frac * kld, frac * nll
+            loss = nll + w * kld + (ce * args.CE_weight if kind == "dagnet" else 0.0)
             samples = relative_to_abs(samples_rel, obs[-1])
             acc[0] += loss[0].double(); acc[1] += kld[0].double(); acc[2] += nll[0].double(); acc[3] += ce[0].double()
             acc[4] += average_displacement_error(samples, gt).double()
             acc[5] += final_displacement_error(samples[-1], gt[-1]).double()
             acc[6] += samples.shape[1]
+    if _dist_on():
+        torch.distributed.all_reduce(acc)
     a = acc.cpu()
     n_scenes = len(loader.dataset)
     return dict(loss=float(a[0]) / n_scenes, kld=float(a[1]) / n_scenes, nll=float(a[2]) / n_scenes, ce=float(a[3]) / n_scenes,
@@ -109,24 +140,34 @@ def _full_adjacency(args, sse, obs, gt):
 def train(args, epch, train_loader, model, warmup, optimizer):
     """train_bsk.py:251-312: one epoch of optimizer steps.  DAG-Net trains on the full obs + pred sequence, A-VRNN and
     VRNN on the observed steps only (models/avrnn/train_bsk.py:256, models/baseline/train_bsk.py:218).
-    ``optimizer`` is an ``_ops.ClipAdam`` (clip_grad_norm_(args.clip) + Adam in one).  -> mean losses per scene."""
+    ``optimizer`` is an ``_ops.ClipAdam`` (clip_grad_norm_(args.clip) + Adam in one).  -> mean losses per scene.
+    Data parallel (torch.distributed initialised, the loader handing every rank its share of each batch): a rank scales
+    its KLD / NLL (means over rows) by its share of the batch's rows so that the all-reduced gradients are the
+    single-process ones; a rank whose share is empty still joins the gradient all-reduce and steps the optimizer; the
+    epoch's loss sums are all-reduced once."""
     kind = _kind(model)
     dev = next(model.parameters()).device
     acc = torch.zeros(4, dtype=torch.float64, device=dev)
     w = float(warmup[epch - 1])
     for data in train_loader:
         obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = _split([t.to(dev) for t in data], kind)
+        frac = _row_fraction(train_loader, obs.shape[1], dev)
+        if obs.shape[1] == 0:
+            training.empty_step(model, optimizer)
+            continue
         if kind == "dagnet":
             assert len(obs) + len(gt) == args.obs_len + args.pred_len
             adj = _full_adjacency(args, sse, obs, gt)
             batch = (torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0),
                      torch.cat((obs_goals, gt_goals), 0).to(torch.int32), sse, adj)
-            r = training.train_step(model, optimizer, batch, kld_weight=w, ce_weight=args.CE_weight)
+            r = training.train_step(model, optimizer, batch, kld_weight=w, ce_weight=args.CE_weight, row_fraction=frac)
         elif kind == "avrnn":
-            r = training.train_step(model, optimizer, (obs_rel, _full_adjacency(args, sse, obs, gt), sse), kld_weight=w)
+            r = training.train_step(model, optimizer, (obs_rel, _full_adjacency(args, sse, obs, gt), sse), kld_weight=w, row_fraction=frac)
         else:
-            r = training.train_step(model, optimizer, (obs_rel,), kld_weight=w)
-        acc[0] += r["loss"][0].double(); acc[1] += r["kld"][0].double(); acc[2] += r["nll"][0].double(); acc[3] += r["ce"][0].double()
+            r = training.train_step(model, optimizer, (obs_rel,), kld_weight=w, row_fraction=frac)
+        acc[0] += r["loss"][0].double(); acc[1] += frac * r["kld"][0].double(); acc[2] += frac * r["nll"][0].double(); acc[3] += r["ce"][0].double()
+    if _dist_on():
+        torch.distributed.all_reduce(acc)
     a = (acc / len(train_loader.dataset)).cpu()
     return dict(loss=float(a[0]), kld=float(a[1]), nll=float(a[2]), ce=float(a[3]))
 
@@ -211,28 +252,54 @@ def load_checkpoint(fn, model, optimizer=None, lr_scheduler=None):
     return ck
 
 
-def fit(args, model, train_loader, valid_loader, test_loader, start_epoch=0, best_ade=float("inf"), on_best=None, seed=None):
+class FitContext:
+    """What the callbacks of ``fit`` get: the live model / optimizer / scheduler / history and ``save(fn)``, which writes the
+    reference's checkpoint dictionary (train_bsk.py:80-93) for the epoch in flight."""
+
+    def __init__(self, args, model, optimizer, lr_scheduler, hist):
+        self.args, self.model, self.optimizer, self.lr_scheduler, self.hist, self.epoch = args, model, optimizer, lr_scheduler, hist, 0
+
+    def save(self, fn):
+        h = self.hist
+        save_checkpoint(fn, self.args, self.epoch, self.model, self.optimizer, self.lr_scheduler, h["best_ade"], h["ade_list_val"],
+                        h["fde_list_val"], h["ade_list_test"], h["fde_list_test"])
+
+
+def fit(args, model, train_loader, valid_loader, test_loader, start_epoch=0, best_ade=float("inf"), on_best=None, on_epoch=None,
+        seed=None, optimizer=None, lr_scheduler=None):
     """The epoch loop of ``main`` (train_bsk.py:382-417): train -> validate -> test per epoch, best-ADE tracking,
-    best-of-``args.num_samples`` evaluation every ``args.eval_every`` epochs.  File handling is the caller's: ``on_best(epoch,
-    ade)`` is invoked where the reference writes its best checkpoint.  -> history dict."""
-    optimizer = _ops.ClipAdam(list(model.parameters()), lr=args.learning_rate, clip=args.clip)
-    training.attach_grad_arena(model, optimizer)
-    sched = PlateauScheduler(optimizer)
+    best-of-``args.num_samples`` evaluation every ``args.eval_every`` epochs.  File handling is the caller's:
+    ``on_best(epoch, ade, ctx)`` is invoked where the reference writes its best checkpoint (:397-405) and
+    ``on_epoch(epoch, ctx)`` at the end of every epoch (periodic / evaluation checkpoints, :408-417); ``ctx`` is a
+    ``FitContext`` (``ctx.save(fn)`` writes the reference's dictionary with optimizer and scheduler state).
+    Resuming (:340-366): build ``optimizer`` / ``lr_scheduler``, restore them with ``load_checkpoint`` and pass them in with
+    ``start_epoch`` / ``best_ade`` - Adam moments, step count, learning rate and plateau counters then carry on.
+    -> history dict."""
+    if optimizer is None:
+        optimizer = _ops.ClipAdam(list(model.parameters()), lr=args.learning_rate, clip=args.clip)
+    if getattr(optimizer, "arena", None) is None:
+        training.attach_grad_arena(model, optimizer)
+    sched = lr_scheduler if lr_scheduler is not None else PlateauScheduler(optimizer)
     warmup = kld_warmup(args.num_epochs, getattr(args, "warmup", False))
-    hist = dict(train=[], val=[], test=[], ade_list_val=[], fde_list_val=[], ade_list_test=[], fde_list_test=[], best_ade=best_ade)
+    hist = dict(train=[], val=[], test=[], ade_list_val=[], fde_list_val=[], ade_list_test=[], fde_list_test=[], best_ade=best_ade,
+                optimizer=optimizer, lr_scheduler=sched)
+    ctx = FitContext(args, model, optimizer, sched, hist)
     for epoch in range(start_epoch + 1, args.num_epochs + 1):
+        ctx.epoch = epoch
+        e_seed = None if seed is None else seed + 7919 * epoch          # fresh evaluation noise every epoch
         hist["train"].append(train(args, epoch, train_loader, model, warmup, optimizer))
-        ade, _ = validate(args, epoch, valid_loader, model, warmup, sched, seed=seed)
+        ade, _ = validate(args, epoch, valid_loader, model, warmup, sched, seed=e_seed)
         hist["val"].append(validate.last)
-        hist["test"].append(test(args, epoch, test_loader, model, warmup, seed=seed))
+        hist["test"].append(test(args, epoch, test_loader, model, warmup, seed=None if e_seed is None else e_seed + 1009))
         if 0 <= ade < hist["best_ade"]:
             hist["best_ade"] = ade
             if on_best is not None:
-                on_best(epoch, ade)
+                on_best(epoch, ade, ctx)
         if getattr(args, "eval_every", 0) and epoch % args.eval_every == 0:
-            a, f = evaluate(args, model, test_loader, args.num_samples, seed=seed)
-            av, fv = evaluate(args, model, valid_loader, args.num_samples, seed=seed)
+            a, f = evaluate(args, model, test_loader, args.num_samples, seed=None if e_seed is None else e_seed + 2003)
+            av, fv = evaluate(args, model, valid_loader, args.num_samples, seed=None if e_seed is None else e_seed + 3001)
             hist["ade_list_test"].append((a, epoch)); hist["fde_list_test"].append((f, epoch))
             hist["ade_list_val"].append((av, epoch)); hist["fde_list_val"].append((fv, epoch))
-    hist["optimizer"], hist["lr_scheduler"] = optimizer, sched
+        if on_epoch is not None:
+            on_epoch(epoch, ctx)
     return hist

@@ -162,6 +162,19 @@ def train_step(model, optimizer: "_ops.ClipAdam", batch, kld_weight=1.0, ce_weig
     return dict(loss=loss.detach(), kld=kld.detach(), nll=nll.detach(), ce=ce.detach())
 
 
+def empty_step(model, optimizer: "_ops.ClipAdam"):
+    """The step of a rank whose share of the batch is empty (a short last batch split over more ranks than it has scenes):
+    zero gradients, the same gradient all-reduce and optimizer step as everybody else, so that the ranks' collectives stay
+    paired and their weights and Adam moments identical."""
+    model.train()
+    optimizer.zero_grad()
+    for p in optimizer.params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    allreduce_gradients(optimizer if getattr(optimizer, "arena", None) is not None else optimizer.params)
+    optimizer.step()
+
+
 class GraphedForwardBackward:
     """Forward + backward of one training step captured once in a hipGraph (torch.cuda.CUDAGraph) and replayed: the
     layer-by-layer step is ~20 000 small launches, which the host cannot issue as fast as the GPU retires them.

@@ -47,17 +47,17 @@ def test_validate_is_the_composition_of_the_pieces(kind, kw):
             if kind == "dagnet":
                 adj = dagnet_amd.adjacency_matrix.compute_adjs_distsim(args, sse, obs, gt)          # dense, as the reference
                 goh = dagnet_amd.utils.to_goals_one_hot(og, args.g_dim)
-                kld, nll, ce, h = model(obs, obs_rel, goh, sse, adj, seed=seed + i)
-                s = model.sample(args.pred_len, h, obs[-1], goh[-1], sse, seed=seed + i)
+                kld, nll, ce, h = model(obs, obs_rel, goh, sse, adj, seed=loop.sub_seed(seed, i, 0))
+                s = model.sample(args.pred_len, h, obs[-1], goh[-1], sse, seed=loop.sub_seed(seed, i, 1))
             elif kind == "avrnn":
                 adj = dagnet_amd.adjacency_matrix.compute_adjs_distsim(args, sse, obs, gt)
-                kld, nll, h = model(obs_rel, adj, seed=seed + i)
+                kld, nll, h = model(obs_rel, adj, seed=loop.sub_seed(seed, i, 0))
                 ce = torch.zeros(1)
-                s = model.sample(args.pred_len, h, obs[-1], sse, seed=seed + i)
+                s = model.sample(args.pred_len, h, obs[-1], sse, seed=loop.sub_seed(seed, i, 1))
             else:
-                kld, nll, h = model(obs_rel, seed=seed + i)
+                kld, nll, h = model(obs_rel, seed=loop.sub_seed(seed, i, 0))
                 ce = torch.zeros(1)
-                s = model.sample(args.pred_len, h, seed=seed + i)
+                s = model.sample(args.pred_len, h, seed=loop.sub_seed(seed, i, 1))
             pred = (obs[-1][None] + torch.cumsum(s, 0)).cpu().double()
             err = (pred - gt.cpu().double()).norm(dim=2)
             w = warm[epch - 1]
@@ -91,7 +91,10 @@ def test_fit_and_checkpoint_round_trip(tmp_path):
     warm = loop.kld_warmup(args.num_epochs, True)
     before = loop.test(args, 1, loader, model, warm, seed=7)
     best = []
-    hist = loop.fit(args, model, loader, loader, loader, on_best=lambda e, a: best.append((e, a)), seed=7)
+    saved = []
+    hist = loop.fit(args, model, loader, loader, loader, on_best=lambda e, a, ctx: best.append((e, a)),
+                    on_epoch=lambda e, ctx: (ctx.save(tmp_path / f"periodic_{e}.pth"), saved.append(e)), seed=7)
+    assert saved == [1, 2] and torch.load(tmp_path / "periodic_1.pth", weights_only=True)["epoch"] == 1
     assert len(hist["train"]) == len(hist["val"]) == len(hist["test"]) == 2 and len(hist["ade_list_test"]) == 1
     assert all(np.isfinite(list(h.values())).all() for h in hist["train"] + hist["val"])
     assert hist["train"][0]["kld"] > 0 and best and hist["best_ade"] == min(a for _, a in best)
@@ -109,3 +112,8 @@ def test_fit_and_checkpoint_round_trip(tmp_path):
     assert opt.step_count == hist["optimizer"].step_count == 4 and torch.equal(opt.m[0], hist["optimizer"].m[0])
     again = loop.test(args, 1, loader, fresh.eval(), warm, seed=7)
     assert again == after
+    # resuming: the restored optimizer / scheduler go back into fit and carry on (step count, moments, learning rate)
+    args.num_epochs = 3
+    h2 = loop.fit(args, fresh, loader, loader, loader, start_epoch=2, best_ade=ck["best_ade"], seed=7, optimizer=opt,
+                  lr_scheduler=loop.PlateauScheduler(opt))
+    assert len(h2["train"]) == 1 and h2["optimizer"] is opt and opt.step_count == 6

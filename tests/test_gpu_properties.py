@@ -225,8 +225,8 @@ def test_evaluate_end_to_end():
     loader = [syn.make_batch([10] * 5, 10, 40, s) for s in (1, 2)]
     ade, fde = evaluate(a, m, loader, num_samples=20, seed=3)
     tot = np.zeros(3)
-    for b in loader:
-        r = rollout_best_of_k(m, a, [t.to(DEV) for t in b], 20, seed=3)
+    for i, b in enumerate(loader):
+        r = rollout_best_of_k(m, a, [t.to(DEV) for t in b], 20, seed=3, batch_index=i)
         tot += [r["ade_sum"].item(), r["fde_sum"].item(), r["n_agents"]]
     assert abs(ade - tot[0] / (tot[2] * 40)) < 1e-9 and abs(fde - tot[1] / tot[2]) < 1e-9 and np.isfinite([ade, fde]).all()
     for kind, kw in (("avrnn", dict(n_layers=1)), ("vrnn", dict(n_layers=2))):
@@ -418,3 +418,33 @@ def test_saturated_gates_and_tanh_stay_exact():
     # yet) and t = 1 (one saturated GRU step and one saturated graph BatchNorm + tanh behind it)
     err = (got[:2] - want[:2]).abs() - (DISP_ATOL + DISP_RTOL * want[:2].abs())
     assert err.max().item() <= 0, f"max abs diff {(got[:2] - want[:2]).abs().max().item():.3e}"
+
+
+def test_chunked_best_of_k_equals_unchunked():
+    """BASELINE configs[4] walks its scenes in chunks (evaluate.best_of_k_chunked): with injected noise the sums must be the
+    un-chunked ones to rounding (scenes are independent, all K samples of a scene stay in one chunk); ragged scenes, a short
+    last chunk."""
+    from dagnet_amd import _capi
+    from dagnet_amd._runtime import scene_ptr_from_sse
+    from dagnet_amd.evaluate import best_of_k_chunked
+    a, m, _ = _model("dagnet", n_layers=2)
+    sizes, K, T = [3, 10, 5, 2, 7, 10, 4], 3, 6
+    a.pred_len = T
+    obs, gt, obs_rel, gt_rel, og, gg, sse = [t.to(DEV) if i < 6 else t for i, t in enumerate(syn.make_batch(sizes, 4, T, 9))]
+    N = obs.shape[1]
+    h = (syn.uniform_noise(9, "h0", (2, N, 64)) - 0.5).to(DEV)
+    eps = syn.uniform_noise(9, "eps", (K, T, N, 32)).to(DEV)
+    q = syn.exp1_noise(9, "q", (K, T, N, 90)).to(DEV)
+    g0 = og[-1].to(torch.int32)
+    whole = m.sample_k(K, T, h, obs[-1], g0, sse, eps=eps, q=q)
+    r = _capi.best_of_k(_capi.HipPlan(None, scene_ptr_from_sse(sse), 1, device=h.device), whole, obs[-1].contiguous(), gt)
+    for chunk in (1, 3, 7, 100):
+        tot = best_of_k_chunked(m, a, K, h, obs[-1], g0, gt, sse, chunk, eps=eps, q=q).cpu()
+        assert float(tot[2]) == N
+        # a scene lands in another tile row than in the whole batch, so its trajectories agree to rounding, not bit for bit
+        assert abs(float(tot[0]) - float(r["sums"][0])) <= 1e-6 * abs(float(r["sums"][0])), chunk
+        assert abs(float(tot[1]) - float(r["sums"][1])) <= 1e-6 * abs(float(r["sums"][1])), chunk
+    # seeded: finite and the same again (every chunk has a stream of its own)
+    t1 = best_of_k_chunked(m, a, K, h, obs[-1], g0, gt, sse, 3, seed=5).cpu()
+    t2 = best_of_k_chunked(m, a, K, h, obs[-1], g0, gt, sse, 3, seed=5).cpu()
+    assert torch.equal(t1, t2) and torch.isfinite(t1).all()

@@ -470,16 +470,9 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     const float *wo = Wo->p, *aop = ao->p;
     const int ninp = std::max(nin, pad), noutp = std::max(nout, pad);
     g.heads = pk.chain([=](int n, int k) { return k < nin ? Wh[n / F][(size_t)k * F + (n % F)] : 0.f; }, P * F, ninp);
-    // a . (x W) == x . (W a): the attention logits' two dot products become 2P extra output features
-    g.fold = pk.chain(
-        [=](int q, int k) {
-            const int p = q % P, half = q / P;
-            double acc = 0.0;
-            if (k >= nin) return 0.f;
-            for (int f = 0; f < F; ++f) acc += (double)Wh[p][(size_t)k * F + f] * (double)ah[p][half * F + f];
-            return (float)(acc * kLog2e);       // logits in the log2 domain: the kernels' softmax is exp2(e - max)
-        },
-        2 * P, ninp);
+    // attention vectors of the heads for the per-lane logit reduction (v2_common.h gat<>): entry 8p+f = a_p[f] (source half)
+    // and 32 + 8p+f = a_p[F+f] (destination half), in the log2 domain: the kernels' softmax is exp2(e - max)
+    g.fold = pk.vec([=](int i) { const int q = i & 31; return (float)((double)ah[q / F][(i >> 5) * F + (q % F)] * kLog2e); }, 64, 64);
     const Tensor *ga = pk.get(prefix + ".bn1.weight", {nout}), *be = pk.get(prefix + ".bn1.bias", {nout});
     const Tensor *mu = pk.get(prefix + ".bn1.running_mean", {nout}), *var = pk.get(prefix + ".bn1.running_var", {nout});
     if (!ga || !be || !mu || !var) return g;
@@ -489,13 +482,15 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     g.out = pk.chain(
         [=](int n, int k) { return n < nout ? (float)(kTanhScale * (gp[n] / sqrtf(vp[n] + 1e-5f)) * wo[(size_t)k * nout + n]) : 0.f; },
         noutp, P * F);
-    g.fold_out = pk.chain(
-        [=](int q, int k) {
+    // a_out . (x2 W_out) == x2 . (W_out a_out): the out head's two logit dot products over its 32 input features
+    g.fold_out = pk.vec(
+        [=](int i) {
+            const int q = i >> 5, k = i & 31;
             double acc = 0.0;
             for (int n = 0; n < nout; ++n) acc += (double)wo[(size_t)k * nout + n] * (double)aop[q * nout + n];
             return (float)(acc * kLog2e);
         },
-        2, P * F);
+        64, 64);
     const int ld = pad32(noutp);
     g.bn = pk.vec(
         [=](int c) {

@@ -21,6 +21,7 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
     static constexpr V2Layout LO = v2_layout(MODEL, NL, ZD, GM);
     const V2Weights &W = MODEL == 3 ? *Wp : LO.off;
     __shared__ float xch[32 * 4 + 64];
+    __shared__ float gfold[GM == 1 ? 2 * GAT_FOLD_FLOATS : 1];      // attention vectors of the hidden / goal GAT (v2_common.h gat_fold_to_lds)
     __shared__ float stash[(MODEL == 2 || MODEL == 4) ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
     float *pos = xch + 128;
     const int lane = threadIdx.x, lc = lane & 31;
@@ -32,6 +33,8 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
     constexpr int GT = V2_GT;
     constexpr int DT = (EXT || MODEL == 4) ? 2 : 1;
     constexpr int MLT = ZD == 32 ? 2 : 1;
+    if constexpr (GRAPH && GM == 1) gat_fold_to_lds(gfold, wp, W.g_hid, lane);
+    if constexpr (HEAD && GM == 1) gat_fold_to_lds(gfold + GAT_FOLD_FLOATS, wp, W.g_goal, lane);
 
     // ---- rows of this wave (K = 1: unit = scene)
     int s0 = lc, n = 1, grow = -1, sid = 0;
@@ -148,7 +151,7 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.g_goal.heads);
             T16 gg[GT];
             if constexpr (GM == 2) pre = gcn<GT, GT>(decg, gg, wp, W.g_goal, adjval, lane, pre, W.lg_goals.w[1]);
-            else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1]);
+            else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, gfold + GAT_FOLD_FLOATS, lane, pre, W.lg_goals.w[1]);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.phi_x2.w[0]);
             finish<0, GT>(gc, wp, W.lg_goals, 0, lh);
             softmax_feat<GT>(gc);
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(64, 2) void forward_v2_kernel(const V2Weights *__re
         if constexpr (GRAPH) {
             T16 hg[2];
             if constexpr (GM == 2) pre = gcn<2, 2>(h[NL - 1], hg, wp, W.g_hid, adjval, lane, pre, W.blend.w[0]);
-            else pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, lane, pre, W.blend.w[0]);
+            else pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, gfold, lane, pre, W.blend.w[0]);
             zero(ta);
             pre = mm<2, 2, false>(ta, wp, W.blend.w[0], hg, lane, pre, W.blend.w[1]);
             pre = mm<2, 2, false>(ta, wp, W.blend.w[1], h[NL - 1], lane, pre, first_off);

@@ -18,9 +18,9 @@ struct V2Lin {
 // out = W2, bn = [2][NT*32] layer-2 scale | shift.
 struct V2Gat {
     int32_t heads;     // chain-packed [1 tile out (P*F = 32)][KT]       (S->T product)
-    int32_t fold;      // chain-packed [1 tile out][KT]: features 0..P-1 = W.a_src, P..2P-1 = W.a_dst
+    int32_t fold;      // [64]: a_src | a_dst of the 4 heads, entry 8p+f = a_p[f] (resp. a_p[F+f]), times log2(e)
     int32_t out;       // chain-packed [NT][1]
-    int32_t fold_out;  // chain-packed [1][1]: feature 0 = W_out.a_src, 1 = W_out.a_dst
+    int32_t fold_out;  // [64]: W_out.a_src | W_out.a_dst over the 32 head features, times log2(e)
     int32_t bn;        // [2][NT*32]: GAT row 0 = folded BatchNorm shift (the scale sits in `out`), row 1 unused
     int32_t nout;
 };
@@ -98,9 +98,9 @@ constexpr V2Layout v2_layout(int model, int nl, int zd, int gm) {
             take(o.bn, u.bn, 2 * nt * 32);
         } else {
             take(o.heads, u.heads, kt * 1024);
-            take(o.fold, u.fold, kt * 1024);
+            take(o.fold, u.fold, 64);
             take(o.out, u.out, nt * 1024);
-            take(o.fold_out, u.fold_out, 1024);
+            take(o.fold_out, u.fold_out, 64);
             take(o.bn, u.bn, 2 * nt * 32);
         }
     };

@@ -35,6 +35,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     static constexpr V2Layout LO = v2_layout(MODEL, NL, ZD, GM);
     const V2Weights &W = MODEL == 3 ? *Wp : LO.off;
     __shared__ float xch[32 * 4 + 64];
+    __shared__ float gfold[GM == 1 ? 2 * GAT_FOLD_FLOATS : 1];      // attention vectors of the hidden / goal GAT (v2_common.h gat_fold_to_lds)
     // DAG-Net: hidden state parked in LDS while the goal head needs the registers ([tile][reg][lane], conflict free)
     // also (NL == 2): the top layer's state is parked while GRU layer 0 runs (its 4 input tiles + 2 state tiles + gate
     // temporaries do not fit beside it; the compiler would spill ~140 registers to scratch memory instead)
@@ -104,6 +105,8 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 
 #pragma unroll
     for (int l = 0; l < NL; ++l) gru_bias_to_lds(gbias + l * GRU_BIAS_FLOATS, wp, W.gru[l], lane);
+    if constexpr (GRAPH && GM == 1) gat_fold_to_lds(gfold, wp, W.g_hid, lane);
+    if constexpr (HEAD && GM == 1) gat_fold_to_lds(gfold + GAT_FOLD_FLOATS, wp, W.g_goal, lane);
     const int first_off = HEAD ? W.dec_goal0.w[0] : W.prior0.w[0];
     WBlk pre = wload(wp, first_off, lane);
 #ifdef DN_PROFILE
@@ -228,14 +231,19 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.g_goal.heads);
             T16 gg[GT];
             if constexpr (GM == 2) pre = gcn<GT, GT>(decg, gg, wp, W.g_goal, adjval, lane, pre, W.lg_goals.w[1]);
-            else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, lane, pre, W.lg_goals.w[1], [&](int i) { PH(i); });
+            else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, gfold + GAT_FOLD_FLOATS, lane, pre, W.lg_goals.w[1], [&](int i) { PH(i); });
             PH(2);
             pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.prior0.w[0]);
             activate<0, GT>(gc);
-            softmax_feat<GT>(gc);
-            // categorical draw: argmax_g exp(p_g) / q_g, q ~ Exp(1).  Branch-free (selects only): features are visited in
-            // increasing order within a lane, so a strict '>' keeps the first maximum; out-of-range features score -1.
-            float best = -1.f;
+            // softmax left unnormalised: gc = exp2(logit - max), p = gc * inv
+            const float pscale = softmax_feat_unnorm<GT>(gc) * 1.44269504088896340736f;
+            // categorical draw: argmax_g exp(p_g) / q_g, q ~ Exp(1) (torch.multinomial on exp(probabilities), utils.py:200-207),
+            // evaluated as argmax_g  p_g log2(e) - log2(q_g)  (a monotone map of the same ratio: one v_log instead of
+            // v_exp + v_rcp per feature, no normalisation pass).  With the Philox stream q = -ln(u), u = n 2^-24, so
+            // log2(q) = log2(24 - log2(n)) + log2(ln 2), and the constant drops out of the argmax.  Branch-free (selects
+            // only): features are visited in increasing order within a lane, so a strict '>' keeps the first maximum;
+            // out-of-range features score -inf.
+            float best = -INFINITY;
             int bi = 0x7fffffff;
             const int Gm1 = R.G - 1;
             const int64_t qrow = row_t * R.G;
@@ -244,22 +252,22 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     const int f0 = nt * 32 + 8 * a + 4 * lh;
-                    float q4[4];
+                    float lq[4];          // log2(q) up to a constant
                     if (R.q) {      // uniform branch; loads are clamped into the row instead of predicated
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) q4[i] = R.q[qrow + min(f0 + i, Gm1)];
+                        for (int i = 0; i < 4; ++i) lq[i] = __builtin_amdgcn_logf(R.q[qrow + min(f0 + i, Gm1)]);
                     } else {
                         const uint4 u = philox4x32(make_uint4(rrow, (uint32_t)tq, (uint32_t)(f0 >> 2), 1u),
                                                       make_uint2((uint32_t)R.seed, (uint32_t)(R.seed >> 32)));
                         const uint32_t u4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) q4[i] = -flog(((float)(u4[i] >> 8) + 1.0f) * (1.0f / 16777216.0f)) + 1e-30f;
+                        for (int i = 0; i < 4; ++i) lq[i] = __builtin_amdgcn_logf(24.0f - __builtin_amdgcn_logf((float)(u4[i] >> 8) + 1.0f));
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         const int f = f0 + i;
-                        float v = fexp(gc[nt][4 * a + i]) * frcp(q4[i]);
-                        v = f <= Gm1 ? v : -1.f;
+                        float v = gc[nt][4 * a + i] * pscale - lq[i];
+                        v = f <= Gm1 ? v : -INFINITY;
                         const bool take = v > best;
                         best = take ? v : best;
                         bi = take ? f : bi;
@@ -433,7 +441,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         if (GRAPH) {
             T16 hg[2];
             if constexpr (GM == 2) pre = gcn<2, 2>(h[NL - 1], hg, wp, W.g_hid, adjval, lane, pre, W.blend.w[0]);
-            else pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, lane, pre, W.blend.w[0]);
+            else pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, gfold, lane, pre, W.blend.w[0]);
             start<2>(ta, wp, W.blend, 0, lh);
             pre = mm<2, 2, false>(ta, wp, W.blend.w[0], hg, lane, pre, W.blend.w[1]);
             pre = mm<2, 2, false>(ta, wp, W.blend.w[1], h[NL - 1], lane, pre, first_off);

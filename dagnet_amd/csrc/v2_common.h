@@ -221,6 +221,26 @@ __device__ __forceinline__ void softmax_feat(T16 (&x)[NT]) {
         for (int r = 0; r < 16; ++r) x[nt][r] = x[nt][r] * inv;
 }
 
+// the same, left unnormalised: x = exp2(logit - max); returns 1 / sum (the goal draw folds it into its score scale)
+template <int NT>
+__device__ __forceinline__ float softmax_feat_unnorm(T16 (&x)[NT]) {
+    float mx = -INFINITY;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, x[nt][r]);
+    mx = hmax(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            x[nt][r] = __builtin_amdgcn_exp2f(x[nt][r] - mx);
+            sum += x[nt][r];
+        }
+    return frcp(hsum(sum));
+}
+
 // attention weights of this lane's row over the 16 tile rows its half owns:
 // alpha[r] = softmax_j( mask ? LeakyReLU(s1 + s2[j]) : -inf ),  j = FR(r) + 4*lh
 // s1, s2 arrive scaled by log2(e) (api.hip v2_gat folds the factor into the logit weights; LeakyReLU commutes with a
@@ -255,31 +275,69 @@ __device__ __forceinline__ float attn_weights(T16 &alpha, float s1, const float 
     return inv;
 }
 
+// Sum over the 8 consecutive lanes of a head (lanes 8p .. 8p+7), the result in all 8: three DPP adds, no LDS round trip
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float red8(float v) {
+    v = dpp_add<0xB1>(v);       // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);       // quad_perm [2,3,0,1]
+    return dpp_add<0x141>(v);   // row_half_mirror: lane i <-> 7 - i of its group of 8, i.e. the other quad's sum
+}
+
+// Attention vectors of one GAT for the per-lane logit arithmetic of gat<> (api.hip v2_gat: fold | fold_out, 128 floats):
+// [a_src 32 | a_dst 32 | w1 32 | w2 32], copied to LDS once per wave
+constexpr int GAT_FOLD_FLOATS = 128;
+__device__ __forceinline__ void gat_fold_to_lds(float *dst, const WBuf &wp, const V2Gat &Gw, int lane) {
+    dst[lane] = wp.ld1(lane * 4, Gw.fold);
+    dst[64 + lane] = wp.ld1(lane * 4, Gw.fold_out);
+}
+
 // Dense GAT (P heads of F features with P*F = 32 -> out_att -> BatchNorm(eval) -> tanh) on the tile.
-// x: KT input tiles (S).  out: NT tiles (S).  xch: per-wave LDS scratch of >= 32*4 floats.
+// x: KT input tiles (S).  out: NT tiles (S).  xch: per-wave LDS scratch of >= 32*4 floats.  gf: gat_fold_to_lds() image.
+// The attention logits s1[p] = a_src[p].Wh_row, s2[p] = a_dst[p].Wh_row are VALU work on the transposed head product
+// (lane = head feature: multiply by the lane's entry of a, sum the 8 lanes of the head with DPP), and the out head's
+// t = (x2 W_out).a_out = x2.(W_out a_out) a 32-term dot product per lane - not 32-wide MFMA tiles with 8 (resp. 2) live
+// output features: 5 + 2 blocks of 16 MFMAs per step of the DAG-Net kernel for ~400 VALU instructions (fp32 MFMAs and
+// VALU share the SIMD's FMA lanes, DESIGN.md 5, so an MFMA tile that is 3/4 padding is pure loss).
 struct NoProf {
     __device__ __forceinline__ void operator()(int) const {}
 };
 // ph: stage timer of the diagnostic build (rollout_v2.hip PH(), tools/phase_profile.py); a no-op otherwise
 template <int KT, int NT, class PF = NoProf>
 __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WBuf &wp, const V2Gat &Gw, unsigned amask,
-                                    float slope, float *xch, int lane, WBlk pre, int next_off, PF ph = PF()) {
+                                    float slope, float *xch, const float *gf, int lane, WBlk pre, int next_off, PF ph = PF()) {
     const int lh = lane >> 5, lc = lane & 31;
     // Wh for all heads, transposed: lane = head feature, register = tile row
-    T16 whT[1], sf[1];
+    T16 whT[1];
     zero(whT);
-    zero(sf);
-    pre = mm<1, KT, true>(whT, wp, Gw.heads, x, lane, pre, Gw.fold);
-    // s1[p] = a_src[p].Wh_row, s2[p] = a_dst[p].Wh_row through folded weights: features 0..3 / 4..7
-    pre = mm<1, KT, false>(sf, wp, Gw.fold, x, lane, pre, Gw.fold_out);
+    const float a_src = gf[lc], a_dst = gf[32 + lc];
+    pre = mm<1, KT, true>(whT, wp, Gw.heads, x, lane, pre, Gw.out);
     ph(10);
+    float u1[16], u2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        u1[r] = red8(whT[0][r] * a_src);
+        u2[r] = red8(whT[0][r] * a_dst);
+    }
+    // register r = 4a + i of half lh is tile row i + 8a + 4 lh: the first lane of every head writes its 16 rows of s1, every
+    // lane picks up its own row's four values, then the same 128 floats carry s2 (read by everybody in the head loop)
+    __syncthreads();
+    if ((lc & 7) == 0) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+            *reinterpret_cast<float4 *>(xch + (lc >> 3) * 32 + 8 * a + 4 * lh) = make_float4(u1[4 * a], u1[4 * a + 1], u1[4 * a + 2], u1[4 * a + 3]);
+    }
+    __syncthreads();
     float s1[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) s1[p] = __shfl(sf[0][p], lc);          // half 0 holds features 0..3
+    for (int p = 0; p < 4; ++p) s1[p] = xch[p * 32 + lc];
     __syncthreads();
-    if (lh == 1) {                                                       // half 1 holds features 4..7 = s2 of the 4 heads
+    if ((lc & 7) == 0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) xch[p * 32 + lc] = sf[0][p];
+        for (int a = 0; a < 4; ++a)
+            *reinterpret_cast<float4 *>(xch + (lc >> 3) * 32 + 8 * a + 4 * lh) = make_float4(u2[4 * a], u2[4 * a + 1], u2[4 * a + 2], u2[4 * a + 3]);
     }
     __syncthreads();
     float mb[16];
@@ -306,13 +364,19 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
         const float v = x2[0][r] * inv[r >> 2];
         x2[0][r] = v > 0.f ? v : fexp(v) - 1.0f;     // ELU
     }
-    // out_att
-    T16 sf2[1];
-    zero(sf2);
-    pre = mm<1, 1, false>(sf2, wp, Gw.fold_out, x2, lane, pre, Gw.out);
-    const float t1 = __shfl(sf2[0][0], lc), t2own = __shfl(sf2[0][1], lc);
+    // out_att logits: this half's 16 features of the row, then the other half's
+    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const float4 w1 = *reinterpret_cast<const float4 *>(gf + 64 + 8 * a + 4 * lh);
+        const float4 w2 = *reinterpret_cast<const float4 *>(gf + 96 + 8 * a + 4 * lh);
+        t1 += x2[0][4 * a] * w1.x + x2[0][4 * a + 1] * w1.y + x2[0][4 * a + 2] * w1.z + x2[0][4 * a + 3] * w1.w;
+        t2 += x2[0][4 * a] * w2.x + x2[0][4 * a + 1] * w2.y + x2[0][4 * a + 2] * w2.z + x2[0][4 * a + 3] * w2.w;
+    }
+    t1 = hsum(t1);
+    t2 = hsum(t2);
     __syncthreads();
-    if (lh == 0) xch[lc] = t2own;
+    if (lh == 0) xch[lc] = t2;
     __syncthreads();
     float s2o[16];
 #pragma unroll

@@ -159,53 +159,182 @@ def copy2d(src, dst, accumulate=False):
     _check(_lib().dagnet_op_copy2d(src.shape[0], src.shape[1], s, lds, d, ldd, int(accumulate), _stream(src.device)))
 
 
-class DeferredGrads:
-    """Weight / bias gradients of sink parameters (training.attach_grad_arena) are summed over the time steps as split
-    partial sums (dagnet_op_gemm_tn_partial) and reduced ONCE at the end of the backward pass (dagnet_op_gemm_tn_finish,
-    queued as an autograd engine callback) instead of once per layer and time step."""
+class StepPool:
+    """Stacked storage for one training step.  Every operator call of a time step is a *site* (numbered in call order, the
+    same in every step); what a site produces for step t - its output in the forward pass, its gradients in the backward
+    pass - is slice t of one persistent [T, ...] buffer per (site, tag).  Consequences:
+      * the saved input and the pre-activation gradient of a layer are contiguous over time, so its weight gradient is ONE
+        [T*M, N]^T [T*M, K] product at the end of the backward pass (DeferredGrads) instead of one product per step;
+      * no allocator traffic inside the step, and fixed addresses for hipGraph capture.
+    Inactive (no training.forward_train in flight): plain torch.empty."""
 
     def __init__(self):
-        self.slots = {}
+        self.bufs = {}
+        self.T, self.t, self.n_site, self.active, self.device = 0, 0, 0, False, None
+
+    def begin(self, T, device):
+        """Sites reserved before the first next_t() are per-step (one slot): stacked weights, loop invariants."""
+        self.T, self.t, self.n_site, self.active, self.device = int(T), -1, 0, True, torch.device(device)
+
+    def next_t(self, t):
+        self.t, self.n_site = int(t), 0
+
+    def end(self):
+        self.active = False
+
+    def site(self):
+        """Reserve the next site of the current time step -> slot (site, t), or None when the pool is not active."""
+        if not self.active:
+            return None
+        self.n_site += 1
+        if self.t < 0:
+            return (("pre", self.n_site - 1), 0, 1)
+        return (self.n_site - 1, self.t, self.T)
+
+    def at(self, slot, tag, shape, like=None, dtype=torch.float32):
+        shape = tuple(int(v) for v in shape)
+        if slot is None:
+            return torch.empty(shape, dtype=dtype, device=like.device if like is not None else self.device)
+        # rows of wide matrices are padded to 16 bytes (g_dim = 90 -> row stride 92): float4 rows for the skinny GEMM
+        pad = len(shape) == 2 and shape[1] > 16 and (shape[1] & 3) != 0
+        full = (shape[0], (shape[1] + 3) & ~3) if pad else shape
+        n = 1
+        for v in full:
+            n *= v
+        key = (slot[0], tag, dtype, self.device)
+        flat = self.bufs.get(key)
+        if flat is None or flat.numel() < slot[2] * n:
+            if flat is not None:
+                _scratch_retired.append(flat)           # a captured graph may still hold its address
+            flat = self.bufs[key] = torch.empty(slot[2] * max(n, 1), dtype=dtype, device=self.device)
+        out = flat[slot[1] * n:(slot[1] + 1) * n].view(full)
+        return out[:, :shape[1]] if pad else out
+
+    def release(self):
+        self.bufs.clear()
+
+
+POOL = StepPool()
+
+
+class DeferredGrads:
+    """Weight / bias gradients of sink parameters (training.attach_grad_arena).  The backward pass only RECORDS the operand
+    pairs (dY_t, X_t) of every layer; at the end of the pass (autograd engine callback) the records of a layer are grouped
+    into runs that are contiguous over time (StepPool slices) and every run is one weight-gradient GEMM over all its steps
+    (a record that is not part of a run falls back to a product of its own)."""
+
+    def __init__(self):
+        self.recs = {}
         self.pending = False
 
     def add(self, key, A, B, dst, gidx=None, bias_dst=None):
         """dst[N,K] (a view of the gradient arena) += A[M,N]^T B[M,K]  (B None: one-hot from gidx); bias_dst[N] += colsum(A)."""
-        lib = _lib()
         M, N = A.shape
-        K = dst.shape[1]
-        key = key + (M, N, K)
-        slot = self.slots.get(key)
-        if slot is None:
-            part = torch.empty(int(lib.dagnet_op_gemm_tn_workspace(M, N, K)), dtype=torch.float32, device=A.device)
-            slot = self.slots[key] = dict(part=part, dst=dst, bias=bias_dst, M=M, N=N, K=K, first=True, dirty=False)
-        (a, lda) = _m(A, "A")
-        b, ldb = (None, 0) if B is None else _m(B, "B")
-        _check(lib.dagnet_op_gemm_tn_partial(a, lda, b, ldb, _p(gidx), int(bias_dst is not None), M, N, K, _p(slot["part"]),
-                                             int(slot["first"]), _stream(A.device)))
-        slot["first"] = False
-        slot["dirty"] = True
+        rec = self.recs.get(key)
+        if rec is None:
+            rec = self.recs[key] = dict(dst=dst, bias=bias_dst, items=[])
+        rec["items"].append((A, B, gidx))
         if not self.pending:
             self.pending = True
             torch.autograd.Variable._execution_engine.queue_callback(self.finish)
 
     def reset(self):
-        """Forget an accumulation that never finished (a backward pass that raised drops the engine callback): without
-        this the next backward would neither queue finish() nor overwrite the stale partial sums."""
+        """Forget an accumulation that never finished (a backward pass that raised drops the engine callback)."""
         self.pending = False
-        for slot in self.slots.values():
-            slot["first"], slot["dirty"] = True, False
+        self.recs.clear()
+
+    def flush(self, key):
+        rec = self.recs.pop(key, None)
+        if rec is None or not rec["items"]:
+            return
+        flush_products(rec["items"], rec["dst"], rec["bias"], True)
 
     def finish(self):
-        lib = _lib()
-        for slot in self.slots.values():
-            if not slot["dirty"]:
-                continue
-            dst = slot["dst"]
-            (c, ldc) = _m(dst, "gradient")
-            _check(lib.dagnet_op_gemm_tn_finish(_p(slot["part"]), c, ldc, _p(slot["bias"]), slot["M"], slot["N"], slot["K"], 1,
-                                                _stream(dst.device)))
-            slot["first"], slot["dirty"] = True, False
+        for key in list(self.recs):
+            self.flush(key)
         self.pending = False
+
+
+def flush_products(items, dst, bias, accumulate):
+    """dst[N,K] (+)= sum over the records (A [M,N], B [M,K] | None, gidx | None) of A^T B, bias[N] (+)= column sums of A.
+    Records whose operands are consecutive slices of stacked matrices (StepPool) are multiplied as ONE product."""
+    lib = _lib()
+    (c, ldc) = _m(dst, "gradient")
+    K = dst.shape[1]
+    i = 0
+    while i < len(items):
+        A, B, gidx = items[i]
+        M, N = A.shape
+        lda = A.stride(0) if M > 1 else N
+        ldb = (B.stride(0) if M > 1 else B.shape[1]) if B is not None else 0
+        j, sign = i + 1, 0
+        while j < len(items):                       # extend the run while every operand advances by exactly one slice
+            A2, B2, g2 = items[j]
+            if A2.shape != A.shape or (B2 is None) != (B is None) or (B is not None and (B2.shape != B.shape or B2.stride(0) != B.stride(0))) \
+                    or A2.stride(0) != A.stride(0):
+                break
+            A1, B1, g1 = items[j - 1]
+            dA = A2.data_ptr() - A1.data_ptr()
+            sg = 1 if dA > 0 else -1
+            if abs(dA) != M * lda * 4 or (sign and sg != sign):
+                break
+            if B is not None and B2.data_ptr() - B1.data_ptr() != sg * M * ldb * 4:
+                break
+            if gidx is not None and g2.data_ptr() - g1.data_ptr() != sg * M * 4:
+                break
+            sign = sg
+            j += 1
+        n = j - i
+        base = items[i] if sign >= 0 else items[j - 1]          # the lowest address of the run
+        Mt = n * M
+        a_ptr = C.c_void_p(base[0].data_ptr())
+        acc = int(bool(accumulate) or i > 0)
+        if B is not None:
+            ws = _ws(A.device, lib.dagnet_op_gemm_tn_workspace(Mt, N, K))
+            _check(lib.dagnet_op_gemm_tn(a_ptr, lda, C.c_void_p(base[1].data_ptr()), ldb, c, ldc, _p(bias), Mt, N, K, _p(ws), acc,
+                                         _stream(A.device)))
+        else:
+            ws = _ws(A.device, lib.dagnet_op_gemm_tn_workspace(Mt, N, K))
+            _check(lib.dagnet_op_onehot_grad(Mt, N, K, a_ptr, lda, C.c_void_p(base[2].data_ptr()), c, ldc, _p(ws), acc, _stream(A.device)))
+        i = j
+
+
+def flush_colsums(items, out, accumulate):
+    """out[N] (+)= column sums of every [M,N] matrix in ``items``; consecutive StepPool slices are reduced as one matrix."""
+    lib = _lib()
+    i = 0
+    while i < len(items):
+        X = items[i]
+        M, N = X.shape
+        j = i + 1
+        sign = 0
+        while j < len(items) and items[j].shape == X.shape and items[j].is_contiguous() and X.is_contiguous():
+            d = items[j].data_ptr() - items[j - 1].data_ptr()
+            sg = 1 if d > 0 else -1
+            if abs(d) != M * N * 4 or (sign and sg != sign):
+                break
+            sign = sg
+            j += 1
+        base = items[i] if sign >= 0 else items[j - 1]
+        Mt = (j - i) * M if X.is_contiguous() else M
+        ws = _ws(X.device, lib.dagnet_op_col_workspace(Mt, N))
+        _check(lib.dagnet_op_colsum(Mt, N, C.c_void_p(base.data_ptr()), X.stride(0) if M > 1 else N, _p(out), int(bool(accumulate) or i > 0),
+                                    _p(ws), _stream(X.device)))
+        i = j
+
+
+class _WAcc:
+    """Gradient bookkeeping of a stacked, non-leaf weight (StackFn output) that is read once per time step: its consumers
+    record their operand pairs, StackFn.backward multiplies them in one go."""
+
+    def __init__(self):
+        self.products, self.colsums = [], []
+
+    def add(self, x, dy):               # d(stacked W [K,N]) += x[M,K]^T dy[M,N]
+        self.products.append((x, dy, None))
+
+    def add_rows(self, part):           # d(stacked a [H,2F]) += column sums of part [S, H*2F]
+        self.colsums.append(part)
 
 
 def _defer(p: torch.Tensor):
@@ -238,7 +367,9 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, W, b, act, slope, cols, gidx, gcol, gdim, *xs):
         N, Ktot = W.shape
         M = xs[0].shape[0]
-        y = _empty(M, N, xs[0])
+        ctx.slot = POOL.site()
+        y = POOL.at(ctx.slot, "y", (M, N), xs[0])
+        ctx.gaccs = [getattr(x, "_hip_gacc", None) for x in xs]
         last = len(xs) - 1
         for s, (x, c0) in enumerate(zip(xs, cols)):
             Ks = x.shape[1]
@@ -262,7 +393,7 @@ class LinearFn(torch.autograd.Function):
         M = y.shape[0]
         dy = _rows(dy)
         if act != ACT_NONE:
-            dpre = _empty(M, N, y)
+            dpre = POOL.at(ctx.slot, "dpre", (M, N), y)
             (g, ldg), (yy, ldy), (dp, ldp) = _m(dy), _m(y), _m(dpre)
             _check(_lib().dagnet_op_act_bwd(M, N, g, ldg, yy, ldy, dp, ldp, act, slope, _stream(y.device)))
         else:
@@ -305,7 +436,13 @@ class LinearFn(torch.autograd.Function):
         dxs = []
         for i, (x, c0) in enumerate(zip(xs, cols)):
             if ctx.needs_input_grad[8 + i]:
-                dx = _empty(M, x.shape[1], y)
+                gacc = ctx.gaccs[i]
+                if gacc is not None:            # a fan-out input (FanoutFn): add into the shared gradient buffer of the tensor
+                    gemm(dpre, W[:, c0:c0 + x.shape[1]], gacc.buffer(x), transb=True, K=N, accumulate=gacc.started)
+                    gacc.started = True
+                    dxs.append(None)
+                    continue
+                dx = POOL.at(ctx.slot, "dx%d" % i, (M, x.shape[1]), y)
                 gemm(dpre, W[:, c0:c0 + x.shape[1]], dx, transb=True, K=N)
                 dxs.append(dx)
             else:
@@ -324,10 +461,13 @@ class MatmulFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, W):
-        y = _empty(x.shape[0], W.shape[1], x)
+        ctx.slot = POOL.site()
+        y = POOL.at(ctx.slot, "y", (x.shape[0], W.shape[1]), x)
         gemm(x, W, y, transb=True)
         ctx.save_for_backward(x, W)
         ctx.W_param = W
+        ctx.gacc = getattr(x, "_hip_gacc", None)
+        ctx.wacc = getattr(W, "_hip_wacc", None)
         return y
 
     @staticmethod
@@ -336,11 +476,17 @@ class MatmulFn(torch.autograd.Function):
         dy = _rows(dy)
         dx = dW = None
         if ctx.needs_input_grad[0]:
-            dx = _empty(x.shape[0], x.shape[1], x)
-            gemm(dy, W, dx)                       # dy [M,N] . W[K,N]^T
+            if ctx.gacc is not None:
+                gemm(dy, W, ctx.gacc.buffer(x), accumulate=ctx.gacc.started)
+                ctx.gacc.started = True
+            else:
+                dx = POOL.at(ctx.slot, "dx", tuple(x.shape), x)
+                gemm(dy, W, dx)                       # dy [M,N] . W[K,N]^T
         if ctx.needs_input_grad[1]:
             sink = _sink(ctx.W_param)
-            if sink is not None and _defer(ctx.W_param) is not None:
+            if ctx.wacc is not None:            # a stacked (non-leaf) weight: StackFn owns the accumulation (one GEMM over all steps)
+                ctx.wacc.add(x, dy)
+            elif sink is not None and _defer(ctx.W_param) is not None:
                 _defer(ctx.W_param).add((id(ctx.W_param), 0), x, dy, sink)
             elif sink is not None:
                 gemm_tn(x, dy, sink, accumulate=True)
@@ -352,26 +498,46 @@ class MatmulFn(torch.autograd.Function):
 
 class StackFn(torch.autograd.Function):
     """[W_0 | W_1 | ...] along the columns (the heads of a GAT evaluated as one GEMM), or flattened row vectors stacked
-    along the rows when ``rows`` (the attention vectors a_p [2F,1] -> [P, 2F])."""
+    along the rows when ``rows`` (the attention vectors a_p [2F,1] -> [P, 2F]).  Inside a training step the stack is built
+    ONCE (training.forward_train hoists it out of the time loop) and carries a _WAcc: its consumers record their operand
+    pairs instead of returning a gradient per time step, and backward() turns them into one product / one column sum."""
 
     @staticmethod
     def forward(ctx, rows, *ws):
+        slot = POOL.site()
         if rows:
             n = ws[0].numel()
-            out = _empty(len(ws), n, ws[0])
+            out = POOL.at(slot, "stack", (len(ws), n), ws[0])
             for i, w in enumerate(ws):
                 copy2d(w.view(1, n), out[i:i + 1])
         else:
             K, F = ws[0].shape
-            out = _empty(K, F * len(ws), ws[0])
+            out = POOL.at(slot, "stack", (K, F * len(ws)), ws[0])
             for i, w in enumerate(ws):
                 copy2d(w, out[:, i * F:(i + 1) * F])
         ctx.rows = rows
         ctx.shapes = [tuple(w.shape) for w in ws]
+        ctx.wacc = _WAcc()
+        ctx.slot = slot
+        ctx.oshape = tuple(out.shape)
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
     def backward(ctx, dout):
+        wacc = ctx.wacc
+        if wacc.products or wacc.colsums:
+            total = POOL.at(ctx.slot, "dstack", ctx.oshape, wacc.products[0][0] if wacc.products else wacc.colsums[0])
+            if wacc.products:
+                flush_products(wacc.products, total, None, False)
+            else:
+                flush_colsums(wacc.colsums, total.view(-1), False)
+            wacc.products, wacc.colsums = [], []
+            if dout is not None:
+                copy2d(_rows(dout), total, accumulate=True)
+            dout = total
+        if dout is None:
+            return (None,) * (1 + len(ctx.shapes))
         dout = _rows(dout)
         grads = []
         for i, shp in enumerate(ctx.shapes):
@@ -385,10 +551,18 @@ class StackFn(torch.autograd.Function):
         return (None, *grads)
 
 
+def stack(rows, *ws):
+    out = StackFn.apply(rows, *ws)
+    if POOL.active and out.grad_fn is not None and hasattr(out.grad_fn, "wacc"):
+        out._hip_wacc = out.grad_fn.wacc
+    return out
+
+
 class SoftmaxFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        y = torch.empty_like(x)
+        ctx.slot = POOL.site()
+        y = POOL.at(ctx.slot, "y", tuple(x.shape), x)
         (xp, ldx), (yp, ldy) = _m(x), _m(y)
         _check(_lib().dagnet_op_softmax_fwd(x.shape[0], x.shape[1], xp, ldx, yp, ldy, _stream(x.device)))
         ctx.save_for_backward(y)
@@ -398,7 +572,7 @@ class SoftmaxFn(torch.autograd.Function):
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
         dy = _rows(dy)
-        dx = torch.empty_like(y)
+        dx = POOL.at(ctx.slot, "dx", tuple(y.shape), y)
         (yp, ldy), (gp, ldg), (xp, ldx) = _m(y), _m(dy), _m(dx)
         _check(_lib().dagnet_op_softmax_bwd(y.shape[0], y.shape[1], yp, ldy, gp, ldg, xp, ldx, _stream(y.device)))
         return dx
@@ -410,8 +584,9 @@ class GruCellFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gi, gh, h):
         M, R = h.shape
-        hn = torch.empty_like(h)
-        gates = _empty(M, 3 * R, h)
+        ctx.slot = POOL.site()
+        hn = POOL.at(ctx.slot, "hn", (M, R), h)
+        gates = POOL.at(ctx.slot, "gates", (M, 3 * R), h)
         _check(_lib().dagnet_op_gru_fwd(M, R, _p(gi), _p(gh), _p(h), _p(hn), _p(gates), _stream(h.device)))
         ctx.save_for_backward(gates, gh, h)
         return hn
@@ -421,7 +596,8 @@ class GruCellFn(torch.autograd.Function):
         gates, gh, h = ctx.saved_tensors
         M, R = h.shape
         dhn = dhn.contiguous()
-        dgi, dgh, dh = _empty(M, 3 * R, h), _empty(M, 3 * R, h), torch.empty_like(h)
+        dgi, dgh, dh = (POOL.at(ctx.slot, "dgi", (M, 3 * R), h), POOL.at(ctx.slot, "dgh", (M, 3 * R), h),
+                        POOL.at(ctx.slot, "dh", (M, R), h))
         _check(_lib().dagnet_op_gru_bwd(M, R, _p(dhn), _p(gates), _p(gh), _p(h), _p(dgi), _p(dgh), _p(dh), _stream(h.device)))
         return dgi, dgh, dh
 
@@ -432,69 +608,161 @@ def _sum_rows(rows: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     return out
 
 
+class LossSumFn(torch.autograd.Function):
+    """scale * sum over all the per-row loss vectors of a step's time steps.  The vectors are StepPool slices, i.e. one
+    contiguous [T*M] array: ONE reduction kernel per loss and step instead of one per time step plus a chain of scalar adds.
+    Backward: every vector gets the incoming scalar gradient (times scale) as a stride-0 view - no kernel."""
+
+    @staticmethod
+    def forward(ctx, scale, *rows):
+        ctx.scale, ctx.shapes = float(scale), [tuple(r.shape) for r in rows]
+        n = rows[0].numel()
+        ptrs = [r.data_ptr() for r in rows]
+        lo = min(ptrs)
+        if all(r.numel() == n and r.is_contiguous() for r in rows) and sorted(ptrs) == [lo + 4 * n * i for i in range(len(rows))]:
+            # one contiguous array of total floats: column sums of its [total / w, w] view (parallel, deterministic), then
+            # the w partial sums in one workgroup (a single workgroup over millions of floats takes milliseconds)
+            total = n * len(rows)
+            w = next(c for c in (64, 32, 16, 8, 4, 2, 1) if total % c == 0)
+            lib = _lib()
+            dev = rows[0].device
+            part = torch.empty(w, dtype=torch.float32, device=dev)
+            ws = _ws(dev, lib.dagnet_op_col_workspace(total // w, w))
+            _check(lib.dagnet_op_colsum(total // w, w, C.c_void_p(lo), w, _p(part), 0, _p(ws), _stream(dev)))
+            out = torch.empty(1, dtype=torch.float32, device=dev)
+            _check(lib.dagnet_op_sum(w, _p(part), ctx.scale, _p(out), 0, _stream(dev)))
+            return out
+        out = torch.empty(1, dtype=torch.float32, device=rows[0].device)
+        for i, r in enumerate(rows):
+            _check(_lib().dagnet_op_sum(r.numel(), _p(r.contiguous()), ctx.scale, _p(out), int(i > 0), _stream(r.device)))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        gs = g.reshape(1) if ctx.scale == 1.0 else g.reshape(1) * ctx.scale
+        return (None, *[gs.expand(shp) for shp in ctx.shapes])
+
+
 class VaeFn(torch.autograd.Function):
-    """z = eps * exp(0.5 logvar_enc) + mean_enc and KLD(enc || prior), MEAN over the rows (models/dagnet/model.py:118-128)."""
+    """z = eps * exp(0.5 logvar_enc) + mean_enc and the per-row KLD(enc || prior) (models/dagnet/model.py:118-128; the mean
+    over the rows and the sum over the steps are LossSumFn's)."""
 
     @staticmethod
     def forward(ctx, mu_e, lv_e, mu_p, lv_p, eps):
         M, Z = mu_e.shape
-        z = torch.empty_like(mu_e)
-        rows = torch.empty(M, dtype=torch.float32, device=mu_e.device)
+        ctx.slot = POOL.site()
+        z = POOL.at(ctx.slot, "z", (M, Z), mu_e)
+        rows = POOL.at(ctx.slot, "rows", (M,), mu_e)
         _check(_lib().dagnet_op_vae_fwd(M, Z, _p(mu_e), _p(lv_e), _p(mu_p), _p(lv_p), _p(eps), _p(z), _p(rows), _stream(mu_e.device)))
         ctx.save_for_backward(mu_e, lv_e, mu_p, lv_p, eps)
-        return z, _sum_rows(rows, 1.0 / M)
+        return z, rows
 
     @staticmethod
     def backward(ctx, dz, dk):
         mu_e, lv_e, mu_p, lv_p, eps = ctx.saved_tensors
         M, Z = mu_e.shape
-        outs = [torch.empty_like(mu_e) for _ in range(4)]
+        outs = [POOL.at(ctx.slot, "d%d" % i, (M, Z), mu_e) for i in range(4)]
         dz = None if dz is None else dz.contiguous()
-        dk = None if dk is None else dk.contiguous()
-        _check(_lib().dagnet_op_vae_bwd(M, Z, _p(mu_e), _p(lv_e), _p(mu_p), _p(lv_p), _p(eps), _p(dz), _p(dk), 1.0 / M, *[_p(o) for o in outs],
+        # dk: the gradient of every row's KLD - one scalar for all rows (LossSumFn hands over a stride-0 view of it)
+        _check(_lib().dagnet_op_vae_bwd(M, Z, _p(mu_e), _p(lv_e), _p(mu_p), _p(lv_p), _p(eps), _p(dz), _scalar_grad(dk), 1.0, *[_p(o) for o in outs],
                                         _stream(mu_e.device)))
         return (*outs, None)
 
 
+def _scalar_grad(g):
+    """Pointer to the one value of a per-row loss gradient that is the same for every row (None -> NULL)."""
+    if g is None:
+        return None
+    if g.numel() > 1 and any(st != 0 for st in g.stride()):
+        raise DagnetHipError("per-row loss vectors must be reduced with LossSumFn (a uniform gradient per row)")
+    return C.c_void_p(g.data_ptr())
+
+
 class NllFn(torch.autograd.Function):
-    """Gaussian negative log-likelihood, MEAN over the rows (models/dagnet/model.py:130-135)."""
+    """Per-row Gaussian negative log-likelihood (models/dagnet/model.py:130-135)."""
 
     @staticmethod
     def forward(ctx, mu, lv, x):
         M, X = mu.shape
-        rows = torch.empty(M, dtype=torch.float32, device=mu.device)
+        ctx.slot = POOL.site()
+        rows = POOL.at(ctx.slot, "rows", (M,), mu)
         _check(_lib().dagnet_op_nll_fwd(M, X, _p(mu), _p(lv), _p(x), _p(rows), _stream(mu.device)))
         ctx.save_for_backward(mu, lv, x)
-        return _sum_rows(rows, 1.0 / M)
+        return rows
 
     @staticmethod
     def backward(ctx, g):
         mu, lv, x = ctx.saved_tensors
-        dmu, dlv = torch.empty_like(mu), torch.empty_like(lv)
-        _check(_lib().dagnet_op_nll_bwd(mu.shape[0], mu.shape[1], _p(mu), _p(lv), _p(x), _p(g.contiguous()), 1.0 / mu.shape[0], _p(dmu), _p(dlv),
+        dmu, dlv = POOL.at(ctx.slot, "dmu", tuple(mu.shape), mu), POOL.at(ctx.slot, "dlv", tuple(lv.shape), lv)
+        _check(_lib().dagnet_op_nll_bwd(mu.shape[0], mu.shape[1], _p(mu), _p(lv), _p(x), _scalar_grad(g), 1.0, _p(dmu), _p(dlv),
                                         _stream(mu.device)))
         return dmu, dlv, None
 
 
 class CeFn(torch.autograd.Function):
-    """-sum_rows p[row, goal[row]]  (the reference's "cross entropy" on probabilities, models/dagnet/model.py:162)."""
+    """Per row -p[row, goal[row]]  (the reference's "cross entropy" on probabilities, models/dagnet/model.py:162)."""
 
     @staticmethod
     def forward(ctx, p, goal):
-        rows = torch.empty(p.shape[0], dtype=torch.float32, device=p.device)
+        ctx.slot = POOL.site()
+        rows = POOL.at(ctx.slot, "rows", (p.shape[0],), p)
         (pp, ldp) = _m(p)
         _check(_lib().dagnet_op_ce_fwd(p.shape[0], pp, ldp, _p(goal), _p(rows), _stream(p.device)))
         ctx.save_for_backward(goal)
         ctx.shape = tuple(p.shape)
-        return _sum_rows(rows)
+        return rows
 
     @staticmethod
     def backward(ctx, g):
         (goal,) = ctx.saved_tensors
         M, G = ctx.shape
-        dp = torch.empty((M, G), dtype=torch.float32, device=goal.device)
-        _check(_lib().dagnet_op_ce_bwd(M, G, _p(goal), _p(g.contiguous()), _p(dp), G, _stream(goal.device)))
+        dp = POOL.at(ctx.slot, "dp", (M, G), goal, dtype=torch.float32)
+        _check(_lib().dagnet_op_ce_bwd(M, G, _p(goal), _scalar_grad(g), _p(dp), dp.stride(0), _stream(goal.device)))
         return dp, None
+
+
+class _GradAcc:
+    """Shared gradient buffer of a tensor with several consumers (FanoutFn)."""
+
+    def __init__(self, slot):
+        self.slot, self.started, self.buf = slot, False, None
+
+    def buffer(self, like):
+        if self.buf is None:
+            self.buf = POOL.at(self.slot, "gacc", tuple(like.shape), like)
+        return self.buf
+
+
+class FanoutFn(torch.autograd.Function):
+    """Identity on a tensor that several layers read.  Autograd would add up the consumers' input gradients one torch add
+    at a time (3 x the tensor's bytes per add); instead the dense layers that read the alias write their input gradient
+    straight into ONE shared buffer (the GEMM epilogue accumulates) and hand autograd nothing; gradients of other consumers
+    arrive the usual way and are added here with one kernel."""
+
+    @staticmethod
+    def forward(ctx, x):
+        out = x.view_as(x)
+        ctx.gacc = _GradAcc(POOL.site())
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        acc = ctx.gacc
+        if not acc.started:
+            return g
+        if g is not None:
+            copy2d(_rows(g), acc.buf, accumulate=True)
+        return acc.buf
+
+
+def fanout(x):
+    """-> an alias of x whose consumers share one gradient buffer (only worth it inside a training step)."""
+    if not POOL.active or not x.requires_grad:
+        return x
+    out = FanoutFn.apply(x)
+    out._hip_gacc = out.grad_fn.gacc if hasattr(out.grad_fn, "gacc") else None
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -505,7 +773,9 @@ class GatAttnFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, Wh, a, adj, plan, H, F, alpha, elu):
-        out = torch.empty_like(Wh)
+        ctx.slot = POOL.site()
+        out = POOL.at(ctx.slot, "out", tuple(Wh.shape), Wh)
+        ctx.wacc = getattr(a, "_hip_wacc", None)
         (w, ldw), (o, ldo) = _m(Wh), _m(out)
         _check(_lib().dagnet_op_gat_attn_fwd(plan._h, _p(adj), _adj_ld(adj), w, ldw, _p(a), H, F, alpha, int(elu), o, ldo, _stream(Wh.device)))
         ctx.save_for_backward(Wh, a, adj, out)
@@ -517,12 +787,15 @@ class GatAttnFn(torch.autograd.Function):
         Wh, a, adj, out = ctx.saved_tensors
         plan, H, F, alpha, elu = ctx.meta
         dout = _rows(dout)
-        dWh = torch.empty_like(Wh)
-        da = torch.empty_like(a)
-        part = torch.empty((plan.S, H * 2 * F), dtype=torch.float32, device=Wh.device)      # per-scene contributions to da
+        dWh = POOL.at(ctx.slot, "dWh", tuple(Wh.shape), Wh)
+        part = POOL.at(ctx.slot, "da_part", (plan.S, H * 2 * F), Wh)      # per-scene contributions to da
         (w, ldw), (o, ldo), (g, ldg), (dw, ldd) = _m(Wh), _m(out), _m(dout), _m(dWh)
         _check(_lib().dagnet_op_gat_attn_bwd(plan._h, _p(adj), _adj_ld(adj), w, ldw, _p(a), H, F, alpha, int(elu), o, ldo, g, ldg, dw, ldd,
                                              _p(part), _stream(Wh.device)))
+        if ctx.wacc is not None:                # stacked attention vectors: one column sum over all time steps (StackFn.backward)
+            ctx.wacc.add_rows(part)
+            return dWh, None, None, None, None, None, None, None
+        da = torch.empty_like(a)
         colsum(part, da)
         return dWh, da, None, None, None, None, None, None
 
@@ -533,9 +806,10 @@ class BnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, tanh_out):
         M, N = x.shape
-        y = torch.empty_like(x)
-        stat = torch.empty(2 * N, dtype=torch.float32, device=x.device)
-        tmp = torch.empty(2 * N, dtype=torch.float32, device=x.device)
+        ctx.slot = POOL.site()
+        y = POOL.at(ctx.slot, "y", (M, N), x)
+        stat = POOL.at(ctx.slot, "stat", (2 * N,), x)
+        tmp = POOL.at(ctx.slot, "tmp", (2 * N,), x)
         ws = _ws(x.device, _lib().dagnet_op_col_workspace(M, N))
         (xp, ldx), (yp, ldy) = _m(x), _m(y)
         _check(_lib().dagnet_op_bn_fwd(M, N, xp, ldx, _p(gamma), _p(beta), eps, momentum, int(tanh_out), yp, ldy, _p(stat),
@@ -549,9 +823,9 @@ class BnFn(torch.autograd.Function):
         x, gamma, stat, y = ctx.saved_tensors
         M, N = x.shape
         dy = _rows(dy)
-        dx = torch.empty_like(x)
+        dx = POOL.at(ctx.slot, "dx", (M, N), x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        sums = torch.empty(2 * N, dtype=torch.float32, device=x.device)
+        sums = POOL.at(ctx.slot, "sums", (2 * N,), x)
         ws = _ws(x.device, _lib().dagnet_op_col_workspace(M, N))
         (xp, ldx), (gp, ldg), (yp, ldy), (dp, ldd) = _m(x), _m(dy), _m(y), _m(dx)
         _check(_lib().dagnet_op_bn_bwd(M, N, xp, ldx, _p(stat), _p(gamma), gp, ldg, yp, ldy, int(ctx.tanh_out), dp, ldd, _p(dgamma),
@@ -564,7 +838,8 @@ class AdjMatmulFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias, adj, plan):
-        y = torch.empty_like(x)
+        ctx.slot = POOL.site()
+        y = POOL.at(ctx.slot, "y", tuple(x.shape), x)
         (xp, ldx), (yp, ldy) = _m(x), _m(y)
         _check(_lib().dagnet_op_adj_matmul(plan._h, x.shape[1], _p(adj), _adj_ld(adj), xp, ldx, _p(bias), 0, yp, ldy, _stream(x.device)))
         ctx.save_for_backward(adj)
@@ -576,7 +851,7 @@ class AdjMatmulFn(torch.autograd.Function):
         (adj,) = ctx.saved_tensors
         plan, has_b = ctx.meta
         dy = _rows(dy)
-        dx = torch.empty_like(dy)
+        dx = POOL.at(ctx.slot, "dx", tuple(dy.shape), dy)
         (gp, ldg), (dp, ldd) = _m(dy), _m(dx)
         _check(_lib().dagnet_op_adj_matmul(plan._h, dy.shape[1], _p(adj), _adj_ld(adj), gp, ldg, None, 1, dp, ldd, _stream(dy.device)))
         db = None
@@ -588,7 +863,7 @@ class AdjMatmulFn(torch.autograd.Function):
 
 def disposition(plan, pos: torch.Tensor, D: int) -> torch.Tensor:
     """d_t [N, D]: every row carries the flattened xy of its scene's agents (models/dagnet/model.py:141-147); no gradient."""
-    out = torch.empty((pos.shape[0], D), dtype=torch.float32, device=pos.device)
+    out = POOL.at(POOL.site(), "d", (pos.shape[0], D), pos)
     _check(_lib().dagnet_op_disposition(plan._h, D, _p(pos.contiguous()), _p(out), D, _stream(pos.device)))
     return out
 
@@ -601,15 +876,20 @@ def bn_train(bn: torch.nn.BatchNorm1d, x: torch.Tensor, tanh_out: bool) -> torch
     return y
 
 
-def gat_train(gat, x, adj, plan):
+def gat_stacks(gat):
+    """The stacked weights of a GAT: all heads' W as one [in, P*F] matrix, their attention vectors as [P, 2F], the out head's
+    as [1, 2*nout].  Built once per training step, outside the time loop."""
+    return (stack(False, *[att.W for att in gat.attentions]), stack(True, *[att.a for att in gat.attentions]),
+            stack(True, gat.out_att.a))
+
+
+def gat_train(gat, x, adj, plan, stacks=None):
     """GAT.forward in train mode (gat_model.py:18-22): P heads -> concat -> out head -> BatchNorm (batch statistics) -> tanh."""
     P, F = gat.nheads, gat.nhid
-    Wcat = StackFn.apply(False, *[att.W for att in gat.attentions])
-    acat = StackFn.apply(True, *[att.a for att in gat.attentions])
+    Wcat, acat, a2 = stacks if stacks is not None else gat_stacks(gat)
     Wh = MatmulFn.apply(x, Wcat)
     x2 = GatAttnFn.apply(Wh, acat, adj, plan, P, F, float(gat.alpha), True)
     Wh2 = MatmulFn.apply(x2, gat.out_att.W)
-    a2 = StackFn.apply(True, gat.out_att.a)
     o = GatAttnFn.apply(Wh2, a2, adj, plan, 1, gat.nout, float(gat.alpha), False)
     return bn_train(gat.bn1, o, True)
 
@@ -633,7 +913,7 @@ def gru_step(rnn: torch.nn.GRU, xs, cols, h_layers):
         else:
             gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, (0,), None, 0, 0, out[-1])
         gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, 0, h_layers[l])
-        out.append(GruCellFn.apply(gi, gh, h_layers[l]))
+        out.append(fanout(GruCellFn.apply(gi, gh, h_layers[l])))      # read by the next layer, the next step, the graph, ...
     return out
 
 

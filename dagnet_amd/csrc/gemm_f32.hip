@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <stdlib.h>
 
 namespace gemm {
 
@@ -205,7 +206,7 @@ struct TnArgs {
 
 // C_split[n][k] = sum over this split's rows m of A[m][n] * B[m][k].  Workgroup tile 64 x 64 (2x2 waves, 1 tile each),
 // reduction chunks of 32 rows; LDS tiles are [m][n] / [m][k] as loaded, operands fetched as ds_read_b32.
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
+__global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const TnArgs p) {
     __shared__ float sA[2][32][64 + 1], sB[2][32][64 + 1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1, lr = lane & 31, lh = lane >> 5;
@@ -296,20 +297,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(const TnArgs p) {
 }
 
 // out[r][c] (+)= sum_s part[s][r][c]   (deterministic second pass of the split reduction; out has row stride ldc)
-// block = 32 outputs x 8 split lanes: coalesced 128-byte reads, fixed summation order
-__global__ __launch_bounds__(256) void reduce_splits_kernel(const float *part, int splits, int N, int K, float *out, int64_t ldc,
-                                                            int accumulate) {
-    __shared__ float red[8][32];
+// block = 32 outputs x 32 split lanes: coalesced 128-byte reads, fixed summation order
+__global__ __launch_bounds__(1024) void reduce_splits_kernel(const float *part, int splits, int N, int K, float *out, int64_t ldc,
+                                                             int accumulate) {
+    __shared__ float red[32][33];
     const int lo = threadIdx.x & 31, lg = threadIdx.x >> 5;
     const int64_t n = (int64_t)N * K;
     const int64_t i = (int64_t)blockIdx.x * 32 + lo;
     float s = 0.f;
     if (i < n)
-        for (int k = lg; k < splits; k += 8) s += part[k * n + i];
+        for (int k = lg; k < splits; k += 32) s += part[k * n + i];
     red[lg][lo] = s;
     __syncthreads();
     if (lg == 0 && i < n) {
-        float t = ((red[0][lo] + red[1][lo]) + (red[2][lo] + red[3][lo])) + ((red[4][lo] + red[5][lo]) + (red[6][lo] + red[7][lo]));
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 32; ++g) t += red[g][lo];
         float *dst = out + (i / K) * ldc + (i % K);
         *dst = accumulate ? *dst + t : t;
     }
@@ -345,11 +348,21 @@ static hipError_t launch_nt_cfg(const NtArgs &a, bool veca, bool vecb, bool tran
 // An operand that is 16-byte aligned with a row stride and a load-direction extent that are multiples of 4 takes float4
 // staging loads, anything else scalar loads.  Tiles: 128x128 for wide outputs, 128x96 / 64x64 / 128x32 for the narrow layers,
 // which are bound by streaming A and C rather than by the MFMAs (small tiles = more workgroups in flight per CU).
+extern "C" hipError_t dn_gemm_skinny(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
+                                     int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
+                                     const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st);
 extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
                               int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
                               const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
     if (act < gemm::ACT_NONE || act > gemm::ACT_RELU) return hipErrorInvalidValue;
+    {   // tall-and-skinny shapes (the training step's layers): weights resident in LDS, A and C streamed by the waves themselves
+        static const bool off = getenv("DAGNET_NO_SKINNY") != nullptr;
+        if (!off) {
+            const hipError_t e = dn_gemm_skinny(A, lda, B, ldb, transb, bias, C, ldc, M, N, K, act, slope, accumulate, gather, gidx, gs_g, gs_n, st);
+            if (e != hipErrorNotSupported) return e;
+        }
+    }
     const bool veca = !((lda & 3) || (K & 3) || (reinterpret_cast<uintptr_t>(A) & 15));
     const bool vecb = !((ldb & 3) || ((transb ? N : K) & 3) || (reinterpret_cast<uintptr_t>(B) & 15));
     gemm::NtArgs a{A, lda, B, ldb, bias, C, ldc, M, N, K, slope, gather, gidx, gs_g, gs_n, act, accumulate};
@@ -374,13 +387,14 @@ extern "C" hipError_t dn_gemm_nt(const float *A, int64_t lda, const float *W, in
 
 // C[N,K] (+)= A[M,N]^T B[M,K], deterministic two-pass split over M.  `part` is a workspace of
 // dn_gemm_tn_workspace(M, N, K) floats.
-// splits over the rows: enough workgroups for 256 CUs x 6 (the kernel is bound by load latency, not by its MFMAs), at least 128 rows each
+// splits over the rows: enough workgroups for 256 CUs x 4 resident ones (the kernel is bound by load latency, not by its MFMAs;
+// 2048 splits gained 10 % on the products and lost it again in the reduction of their partial sums), at least 128 rows each
 extern "C" int64_t dn_gemm_tn_splits(int M, int N, int K) {
     const int64_t blocks = (int64_t)((N + 63) / 64) * ((K + 63) / 64);
-    int64_t s = (1536 + blocks - 1) / blocks;
+    int64_t s = (1024 + blocks - 1) / blocks;
     const int64_t cap = (M + 127) / 128;
     if (s > cap) s = cap;
-    return s < 1 ? 1 : (s > 512 ? 512 : s);
+    return s < 1 ? 1 : (s > 1024 ? 1024 : s);
 }
 extern "C" int64_t dn_gemm_tn_workspace(int M, int N, int K) { return dn_gemm_tn_splits(M, N, K) * ((int64_t)N * K + N); }
 // dbias (nullable): [N] (+)= column sums of A, computed by the same pass over A (the bias gradient of the layer).
@@ -404,10 +418,10 @@ extern "C" hipError_t dn_gemm_tn_staged(const float *A, int64_t lda, const float
     }
     if (stages & 2) {
         const int64_t n = (int64_t)N * K;
-        hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, st, part, splits, N, K, C, ldc,
+        hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((n + 31) / 32)), dim3(1024), 0, st, part, splits, N, K, C, ldc,
                            accumulate);
         if (want_bias && dbias)
-            hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((N + 31) / 32)), dim3(256), 0, st, bias_part, splits, 1, N,
+            hipLaunchKernelGGL(gemm::reduce_splits_kernel, dim3((unsigned)((N + 31) / 32)), dim3(1024), 0, st, bias_part, splits, 1, N,
                                dbias, (int64_t)N, accumulate);
     }
     return hipGetLastError();

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import _capi, _ops
-from ._ops import ACT_LRELU, ACT_NONE, ACT_RELU, CeFn, NllFn, SoftmaxFn, VaeFn, gat_train, gcn_train, gru_step, linear
+from ._ops import ACT_LRELU, ACT_NONE, ACT_RELU, CeFn, LossSumFn, NllFn, SoftmaxFn, VaeFn, gat_train, gcn_train, gru_step, linear
 
 _PLANS: "OrderedDict[tuple, _capi.HipPlan]" = OrderedDict()
 
@@ -61,9 +61,9 @@ def _mlp2(seq, xs, cols, gidx=None, gcol=0, gdim=0):
     return linear(seq[2], [h], [0], act=ACT_LRELU)
 
 
-def _graph(mod, x, adj_t, plan):
+def _graph(mod, x, adj_t, plan, stacks=None):
     from .gat import GAT
-    return gat_train(mod, x, adj_t, plan) if isinstance(mod, GAT) else gcn_train(mod, x, adj_t, plan)
+    return gat_train(mod, x, adj_t, plan, stacks) if isinstance(mod, GAT) else gcn_train(mod, x, adj_t, plan)
 
 
 def _eps(eps, t, N, Z, device):
@@ -77,7 +77,13 @@ def _f32(t):
 
 
 def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, eps=None):
-    """-> (KLD[1], NLL[1], CE[1], h[L,N,R]); differentiable w.r.t. the parameters of ``model``."""
+    """-> (KLD[1], NLL[1], CE[1], h[L,N,R]); differentiable w.r.t. the parameters of ``model``.
+
+    Storage comes from _ops.POOL: what an operator produces at time step t is slice t of one stacked buffer per call site,
+    so that every layer's weight gradient is one product over all steps at the end of the backward pass; tensors with
+    several consumers go through _ops.fanout (one shared input-gradient buffer instead of a chain of torch adds); the
+    per-row losses of all steps are summed by one kernel each (_ops.LossSumFn); the stacked GAT weights are built once."""
+    from .gat import GAT
     kind = {"VRNN": "vrnn", "AVRNN": "avrnn", "DAGNet": "dagnet"}[type(model).__name__]
     dev = traj_rel.device
     if not traj_rel.is_cuda:
@@ -92,45 +98,61 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
         goals = goals.to(torch.int32).contiguous()
     if eps is not None:
         eps = _f32(eps)
-    h = [torch.zeros((N, R), dtype=torch.float32, device=dev) for _ in range(L)]
-    zero = torch.zeros(1, dtype=torch.float32, device=dev)
-    kld, nll, ce = zero, zero, zero
-    for t in range(1, T):
-        x_t = traj_rel[t]
-        hl = h[-1]
-        if kind == "dagnet":
-            d_t = _ops.disposition(plan, traj[t], D)
-            g_prev, g_t = goals[t - 1], goals[t]
-            hid = linear(model.dec_goal[0], [d_t, hl], [0, D], act=ACT_RELU, gidx=g_prev, gcol=D + R, gdim=G)
-            dec_g = SoftmaxFn.apply(linear(model.dec_goal[2], [hid], [0]))
-            g_graph = _graph(model.graph_goals, dec_g, adj[t], plan)
-            g_comb = SoftmaxFn.apply(linear(model.lg_goals[0], [dec_g, g_graph], [0, G]))
-            ce = ce + CeFn.apply(g_comb, g_t)
-            phi_x = _mlp2(model.phi_x, [x_t], [0])
-            enc = _mlp2(model.enc, [phi_x, hl], [0, H + G], gidx=g_t, gcol=H, gdim=G)
-            prior = _mlp2(model.prior, [hl], [G], gidx=g_t, gcol=0, gdim=G)
-        else:
-            phi_x = _mlp2(model.phi_x, [x_t], [0])
-            enc = _mlp2(model.enc, [phi_x, hl], [0, H])
-            prior = _mlp2(model.prior, [hl], [0])
-        mu_e, lv_e = linear(model.enc_mean, [enc], [0]), linear(model.enc_logvar, [enc], [0])
-        mu_p, lv_p = linear(model.prior_mean, [prior], [0]), linear(model.prior_logvar, [prior], [0])
-        z, k = VaeFn.apply(mu_e, lv_e, mu_p, lv_p, _eps(eps, t, N, Z, dev))
-        phi_z = _mlp2(model.phi_z, [z], [0])
-        if kind == "dagnet":
-            dec = _mlp2(model.dec, [d_t, phi_z, hl], [0, D + G, D + G + H], gidx=g_t, gcol=D, gdim=G)
-        else:
-            dec = _mlp2(model.dec, [phi_z, hl], [0, H])
-        mu_d, lv_d = linear(model.dec_mean, [dec], [0]), linear(model.dec_logvar, [dec], [0])
-        h = gru_step(model.rnn, [phi_x, phi_z], [0, H], h)
-        kld = kld + k
-        nll = nll + NllFn.apply(mu_d, lv_d, x_t)
+    fan = _ops.fanout
+    pool = _ops.POOL
+    pool.begin(T, dev)
+    try:
+        graph = blend = None
+        st_goal = st_hid = None
         if kind != "vrnn":
             graph = model.graph_hiddens if kind == "dagnet" else model.graph
             blend = model.lg_hiddens if kind == "dagnet" else model.lg
-            h_g = _graph(graph, h[-1], adj[t], plan)
-            h[-1] = linear(blend, [h_g, h[-1]], [0, R])
-    return kld, nll, ce, torch.stack(h, 0)
+            st_hid = _ops.gat_stacks(graph) if isinstance(graph, GAT) else None
+            if kind == "dagnet" and isinstance(model.graph_goals, GAT):
+                st_goal = _ops.gat_stacks(model.graph_goals)
+        h = [torch.zeros((N, R), dtype=torch.float32, device=dev) for _ in range(L)]
+        k_rows, n_rows, c_rows = [], [], []
+        for t in range(1, T):
+            pool.next_t(t)
+            x_t = traj_rel[t]
+            hl = h[-1]
+            if kind == "dagnet":
+                d_t = _ops.disposition(plan, traj[t], D)
+                g_prev, g_t = goals[t - 1], goals[t]
+                hid = linear(model.dec_goal[0], [d_t, hl], [0, D], act=ACT_RELU, gidx=g_prev, gcol=D + R, gdim=G)
+                dec_g = fan(SoftmaxFn.apply(linear(model.dec_goal[2], [hid], [0])))
+                g_graph = _graph(model.graph_goals, dec_g, adj[t], plan, st_goal)
+                g_comb = SoftmaxFn.apply(linear(model.lg_goals[0], [dec_g, g_graph], [0, G]))
+                c_rows.append(CeFn.apply(g_comb, g_t))
+                phi_x = fan(_mlp2(model.phi_x, [x_t], [0]))
+                enc = fan(_mlp2(model.enc, [phi_x, hl], [0, H + G], gidx=g_t, gcol=H, gdim=G))
+                prior = fan(_mlp2(model.prior, [hl], [G], gidx=g_t, gcol=0, gdim=G))
+            else:
+                phi_x = fan(_mlp2(model.phi_x, [x_t], [0]))
+                enc = fan(_mlp2(model.enc, [phi_x, hl], [0, H]))
+                prior = fan(_mlp2(model.prior, [hl], [0]))
+            mu_e, lv_e = linear(model.enc_mean, [enc], [0]), linear(model.enc_logvar, [enc], [0])
+            mu_p, lv_p = linear(model.prior_mean, [prior], [0]), linear(model.prior_logvar, [prior], [0])
+            z, k = VaeFn.apply(mu_e, lv_e, mu_p, lv_p, _eps(eps, t, N, Z, dev))
+            k_rows.append(k)
+            phi_z = fan(_mlp2(model.phi_z, [z], [0]))
+            if kind == "dagnet":
+                dec = fan(_mlp2(model.dec, [d_t, phi_z, hl], [0, D + G, D + G + H], gidx=g_t, gcol=D, gdim=G))
+            else:
+                dec = fan(_mlp2(model.dec, [phi_z, hl], [0, H]))
+            mu_d, lv_d = linear(model.dec_mean, [dec], [0]), linear(model.dec_logvar, [dec], [0])
+            h = gru_step(model.rnn, [phi_x, phi_z], [0, H], h)
+            n_rows.append(NllFn.apply(mu_d, lv_d, x_t))
+            if kind != "vrnn":
+                h_g = _graph(graph, h[-1], adj[t], plan, st_hid)
+                h[-1] = fan(linear(blend, [h_g, h[-1]], [0, R]))
+        zero = torch.zeros(1, dtype=torch.float32, device=dev)
+        kld = LossSumFn.apply(1.0 / N, *k_rows) if k_rows else zero
+        nll = LossSumFn.apply(1.0 / N, *n_rows) if n_rows else zero
+        ce = LossSumFn.apply(1.0, *c_rows) if c_rows else zero
+        return kld, nll, ce, torch.stack(h, 0)
+    finally:
+        pool.end()
 
 
 def train_step(model, optimizer: "_ops.ClipAdam", batch, kld_weight=1.0, ce_weight=1.0, eps=None, row_fraction=1.0):

@@ -1,0 +1,69 @@
+"""GPU: dagnet_op_gemm on the tall-and-skinny shapes of the training step (csrc/gemm_skinny.hip takes M >= 2048, N <= 192, K <= 96
+with 16-byte rows; everything else the LDS-tiled kernel of csrc/gemm_f32.hip) against torch's fp32 matmul: every epilogue
+(bias, one-hot gather, activation, accumulate), both operand orders, padded row strides, K and N that are not multiples
+of 4 or 32, a row count that is not a multiple of 32."""
+import pytest
+import torch
+
+from dagnet_amd import _ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _padded(M, N, gen, nan_pad=True):
+    """[M, N] view of an [M, ceil4(N)] buffer whose padding holds NaN (the kernels must never let it leak into a result)."""
+    ld = (N + 3) & ~3
+    buf = torch.full((M, ld), float("nan") if nan_pad else 0.0, device=DEV)
+    buf[:, :N] = torch.randn((M, N), generator=gen).to(DEV)
+    return buf[:, :N]
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 64, 64), (5000, 90, 64), (2049, 64, 90), (3000, 192, 64), (2100, 32, 20), (2500, 90, 90),
+                                   (2048, 2, 64), (2300, 64, 2), (4000, 64, 32), (1000, 64, 64), (4100, 64, 192), (2200, 90, 180),
+                                   (2500, 20, 130), (2100, 128, 192)])
+@pytest.mark.parametrize("transb", [False, True])
+def test_gemm_matches_torch(M, N, K, transb):
+    g = torch.Generator().manual_seed(M + N + K)
+    A = _padded(M, K, g)
+    W = (torch.randn((K, N) if transb else (N, K), generator=g) / K ** 0.5).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = A.double() @ (W.double() if transb else W.double().t())
+    tol = dict(rtol=2e-5, atol=2e-5)
+    # plain
+    C = _padded(M, N, g)
+    _ops.gemm(A, W, C, transb=transb)
+    torch.testing.assert_close(C.double(), ref, **tol)
+    # bias + LeakyReLU
+    C = _padded(M, N, g)
+    _ops.gemm(A, W, C, transb=transb, bias=bias, act=_ops.ACT_LRELU, slope=0.01)
+    torch.testing.assert_close(C.double(), torch.nn.functional.leaky_relu(ref + bias.double(), 0.01), **tol)
+    # accumulate into existing values, tanh
+    C0 = torch.randn((M, N), generator=g).to(DEV)
+    C = _padded(M, N, g)
+    C.copy_(C0)
+    _ops.gemm(A, W, C, transb=transb, accumulate=True, act=_ops.ACT_TANH)
+    torch.testing.assert_close(C.double(), torch.tanh(C0.double() + ref), **tol)
+    # one-hot input as a gather of table rows (LinearFn: table = columns of a wider weight matrix) + ReLU
+    G = 37
+    table = torch.randn((N, G + 5), generator=g).to(DEV)             # element (g, n) = table[n, 3 + g]
+    idx = torch.randint(0, G, (M,), generator=g).to(torch.int32).to(DEV)
+    C = _padded(M, N, g)
+    import ctypes
+    _ops.gemm(A, W, C, transb=transb, bias=bias, act=_ops.ACT_RELU, gather=ctypes.c_void_p(table.data_ptr() + 4 * 3), gidx=idx, gs_g=1,
+              gs_n=G + 5)
+    want = torch.relu(ref + bias.double() + table[:, 3:3 + G].double().t()[idx.long()])
+    torch.testing.assert_close(C.double(), want, **tol)
+
+
+def test_gemm_unpadded_rows_take_the_tiled_kernel():
+    """Contiguous [M, 90] operands (row stride not a multiple of 4) are not eligible for the skinny kernel: same answer."""
+    g = torch.Generator().manual_seed(5)
+    A = torch.randn((3000, 90), generator=g).to(DEV)
+    W = torch.randn((64, 90), generator=g).to(DEV)
+    C = torch.empty((3000, 64), device=DEV)
+    _ops.gemm(A, W, C)
+    torch.testing.assert_close(C.double(), A.double() @ W.double().t(), rtol=2e-5, atol=5e-5)
+    C2 = torch.empty((3000, 90), device=DEV)
+    _ops.gemm(C, W, C2, transb=True)
+    torch.testing.assert_close(C2.double(), C.double() @ W.double(), rtol=2e-5, atol=2e-4)

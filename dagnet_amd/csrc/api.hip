@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -29,6 +30,10 @@ extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, i
 extern "C" int dn_v2_has(int model, int n_layers, int z_dim, int graph);
 extern "C" hipError_t dn_launch_forward_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *w, const V2Run *r, hipStream_t st);
 extern "C" hipError_t dn_launch_loss_finalize(int n_tiles, int N, const double *part, double *losses, hipStream_t st);
+extern "C" hipError_t dn_launch_nan_rows(int64_t rows, const DnNanSrc *src, const DnNanDst *dst, double *losses, void *marker,
+                                         hipStream_t st);
+extern "C" hipError_t dn_launch_nan_spread(const void *marker, int marker_is_double, void *base, int chunks, int64_t chunk_stride,
+                                           int64_t len, hipStream_t st);
 extern "C" hipError_t dn_launch_abs_errors(int T, int N, const float *pred, const float *gt, float *ade, float *fde, hipStream_t st);
 extern "C" hipError_t dn_launch_scene_min_sum(const int32_t *scene_ptr, int S, int N, int K, const float *ade, const float *fde,
                                               float *scene_best, double *sums, hipStream_t st);
@@ -119,6 +124,12 @@ struct dagnet_plan {
     bool wide = false;
     float *d_wide = nullptr;
     WideBuffers wb;
+    // calls that write the plan's own buffers (loss partials, wide / big-G workspace) must not overlap: the last such call's
+    // completion event and stream (plan_enter / plan_leave)
+    mutable std::mutex mu;
+    mutable hipEvent_t busy = nullptr;
+    mutable hipStream_t busy_stream = nullptr;
+    mutable bool armed = false;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1079,6 +1090,7 @@ extern "C" void dagnet_plan_destroy(dagnet_plan *p) {
     void *ptrs[] = {p->d_scene_ptr, p->d_tile_u0, p->d_tile_nu, p->d_row_scene, p->d_off_dense, p->d_off_compact, p->d_loss_part, p->d_static, p->d_tile2_u0, p->d_tile2_nu, p->d_gscratch, p->d_wide};
     for (void *q : ptrs)
         if (q) (void)hipFree(q);
+    if (p->busy) (void)hipEventDestroy(p->busy);
     delete p;
 }
 
@@ -1143,19 +1155,59 @@ static void fill_common(DnParams &P, const dagnet_model *m, const dagnet_plan *p
 #endif
 }
 
-extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_h0, const float *d_x0,
-                             const int32_t *d_g0, const float *d_eps, const float *d_q, const int32_t *d_force_goals, uint64_t seed,
-                             float *d_out, int32_t *d_out_goals, void *stream) {
+
+// ---------------------------------------------------------------------------------------------
+// Hazard guards
+// ---------------------------------------------------------------------------------------------
+// A plan's workspace (loss partials of the teacher-forced pass, state and layer buffers of the wide goal head, goal slabs of big-G
+// plans) is written by the calls that use it, so two such calls on one plan may not be in flight at once.  Calls on the same
+// stream order themselves; a call on ANOTHER stream while the previous one has not completed is refused here instead of
+// corrupting both results.  Streams under graph capture are not tracked (an event recorded into a capture cannot be queried).
+static bool stream_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return cs != hipStreamCaptureStatusNone;
+}
+
+static int plan_enter(const dagnet_plan *p, hipStream_t st, const char *what) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->armed || p->busy_stream == st || stream_capturing(st)) return DAGNET_OK;
+    const hipError_t q = hipEventQuery(p->busy);
+    if (q == hipErrorNotReady) {
+        (void)hipGetLastError();
+        return fail(DAGNET_ERR_INVALID, "%s: the plan's workspace is still in use by a call on another stream; calls on one plan must "
+                    "not overlap (use one plan per stream, or synchronize)", what);
+    }
+    if (q != hipSuccess) return fail(DAGNET_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+    return DAGNET_OK;
+}
+
+static int plan_leave(const dagnet_plan *p, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (stream_capturing(st)) return DAGNET_OK;
+    if (!p->busy) HIP_TRY(hipEventCreateWithFlags(&p->busy, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(p->busy, st));
+    p->busy_stream = st;
+    p->armed = true;
+    return DAGNET_OK;
+}
+
+// NaN in the state a call starts from (h0 / x0, or the observed trajectory): poison what the reference would poison
+// (aux_kernels.hip dn_nan_rows_kernel / dn_nan_spread_kernel).  Runs after the call's kernels on the same stream.
+static DnNanSrc nan_src(const void *p, int64_t plane_stride, int planes, int cols) {
+    return DnNanSrc{static_cast<const uint32_t *>(p), plane_stride, planes, cols};
+}
+static DnNanDst nan_dst(void *p, int64_t plane_stride, int64_t planes, int cols) {
+    return DnNanDst{static_cast<uint32_t *>(p), plane_stride, planes, cols};
+}
+
+static int sample_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_h0, const float *d_x0,
+                       const int32_t *d_g0, const float *d_eps, const float *d_q, const int32_t *d_force_goals, uint64_t seed,
+                       float *d_out, int32_t *d_out_goals, void *stream) {
     if (!m || !p) return fail(DAGNET_ERR_INVALID, "null argument");
-    if (T < 0) return fail(DAGNET_ERR_INVALID, "T must be >= 0");
-    if (T == 0) return DAGNET_OK;          // nothing to roll out (the output tensor is empty)
-    if (!d_h0 || !d_out) return fail(DAGNET_ERR_INVALID, "null argument");
-    if (m->dims.model == DAGNET_MODEL_GRAPH) return fail(DAGNET_ERR_INVALID, "stand-alone graph modules have no sample()");
-    if (m->dims.model != DAGNET_MODEL_VRNN && !d_x0) return fail(DAGNET_ERR_INVALID, "x_abs_start is required for graph models");
-    if (m->dims.model == DAGNET_MODEL_DAGNET && !d_g0) return fail(DAGNET_ERR_INVALID, "g_start is required for DAG-Net");
-    if (m->dims.model == DAGNET_MODEL_DAGNET && 2 * p->AS > m->dims.D) return fail(DAGNET_ERR_INVALID, "plan was made for another model");
-    if (T == 0) return DAGNET_OK;
-    if (int rc = check_plan(m, p)) return rc;
     if (m->v2 && p->n_tiles2 > 0 && !getenv("DAGNET_FORCE_GENERIC")) {
         V2Run r;
         memset(&r, 0, sizeof(r));
@@ -1214,6 +1266,41 @@ extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_
     return DAGNET_OK;
 }
 
+extern "C" int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_h0, const float *d_x0,
+                             const int32_t *d_g0, const float *d_eps, const float *d_q, const int32_t *d_force_goals, uint64_t seed,
+                             float *d_out, int32_t *d_out_goals, void *stream) {
+    if (!m || !p) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (T < 0) return fail(DAGNET_ERR_INVALID, "T must be >= 0");
+    if (T == 0) return DAGNET_OK;          // nothing to roll out (the output tensor is empty)
+    if (!d_h0 || !d_out) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (m->dims.model == DAGNET_MODEL_GRAPH) return fail(DAGNET_ERR_INVALID, "stand-alone graph modules have no sample()");
+    if (m->dims.model != DAGNET_MODEL_VRNN && !d_x0) return fail(DAGNET_ERR_INVALID, "x_abs_start is required for graph models");
+    if (m->dims.model == DAGNET_MODEL_DAGNET && !d_g0) return fail(DAGNET_ERR_INVALID, "g_start is required for DAG-Net");
+    if (m->dims.model == DAGNET_MODEL_DAGNET && 2 * p->AS > m->dims.D) return fail(DAGNET_ERR_INVALID, "plan was made for another model");
+    if (int rc = check_plan(m, p)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // the register-resident kernel keeps all state in registers; the wide-head and big-G paths work in the plan's buffers
+    const bool owns = !(m->v2 && p->n_tiles2 > 0) && (p->wide || p->big);
+    if (owns)
+        if (int rc = plan_enter(p, st, "dagnet_sample")) return rc;
+    if (int rc = sample_impl(m, p, T, d_h0, d_x0, d_g0, d_eps, d_q, d_force_goals, seed, d_out, d_out_goals, stream)) return rc;
+    const bool graph = m->dims.model != DAGNET_MODEL_VRNN;
+    const int64_t plane = (int64_t)p->N * 2;                      // out is [K][T][N][2]
+    // (h0 only: the start positions enter through the adjacency alone, where the reference's own `adj > 0` mask drops a NaN)
+    const DnNanSrc src[2] = {nan_src(d_h0, (int64_t)p->N * m->dims.R, m->dims.L, m->dims.R), nan_src(nullptr, 0, 0, 0)};
+    if (!graph) {               // independent rows: the row's own trajectory, every step
+        const DnNanDst dst = nan_dst(d_out, plane, (int64_t)p->K * T, 2);
+        HIP_TRY(dn_launch_nan_rows(p->N, src, &dst, nullptr, nullptr, st));
+    } else {                    // step 0 of the row; from step 1 on the graph has spread it over the batch
+        const DnNanDst dst = nan_dst(d_out, plane * T, p->K, 2);
+        float *marker = T > 1 ? d_out + plane : nullptr;
+        HIP_TRY(dn_launch_nan_rows(p->N, src, &dst, nullptr, marker, st));
+        if (T > 1) HIP_TRY(dn_launch_nan_spread(marker, 0, marker, p->K, plane * T, plane * (T - 1), st));
+    }
+    if (owns) return plan_leave(p, st);
+    return DAGNET_OK;
+}
+
 static int set_adj(DnParams &P, const dagnet_plan *p, const float *d_adj, int64_t adj_dense_ld) {
     if (!d_adj) return fail(DAGNET_ERR_INVALID, "adjacency is required for graph models");
     if (adj_dense_ld != 0 && adj_dense_ld != p->N) return fail(DAGNET_ERR_INVALID, "adj_dense_ld must be 0 (compact) or N");
@@ -1224,16 +1311,9 @@ static int set_adj(DnParams &P, const dagnet_plan *p, const float *d_adj, int64_
     return DAGNET_OK;
 }
 
-extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_traj, const float *d_traj_rel,
-                              const int32_t *d_goals, const float *d_adj, int64_t adj_dense_ld, const float *d_eps, uint64_t seed,
-                              double *d_losses, float *d_h_out, void *stream) {
-    if (!m || !p || !d_traj_rel || !d_losses || !d_h_out) return fail(DAGNET_ERR_INVALID, "null argument");
-    if (p->K != 1) return fail(DAGNET_ERR_INVALID, "forward needs a plan with n_samples == 1");
-    if (T < 1) return fail(DAGNET_ERR_INVALID, "T must be >= 1");
-    if (m->dims.model == DAGNET_MODEL_GRAPH) return fail(DAGNET_ERR_INVALID, "stand-alone graph modules have no forward pass");
-    const bool dag = m->dims.model == DAGNET_MODEL_DAGNET;
-    if (dag && (!d_traj || !d_goals)) return fail(DAGNET_ERR_INVALID, "traj and goals are required for DAG-Net");
-    if (int rc = check_plan(m, p)) return rc;
+static int forward_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_traj, const float *d_traj_rel,
+                        const int32_t *d_goals, const float *d_adj, int64_t adj_dense_ld, const float *d_eps, uint64_t seed,
+                        double *d_losses, float *d_h_out, void *stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     DnParams P;
     fill_common(P, m, p);
@@ -1308,6 +1388,28 @@ extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32
     HIP_TRY(dn_launch_rollout(1, p->d_static, &P.r, (size_t)p->lds.total * 4, st));
     HIP_TRY(dn_launch_loss_finalize(p->n_tiles, p->N, p->d_loss_part, d_losses, st));
     return DAGNET_OK;
+}
+
+extern "C" int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_traj, const float *d_traj_rel,
+                              const int32_t *d_goals, const float *d_adj, int64_t adj_dense_ld, const float *d_eps, uint64_t seed,
+                              double *d_losses, float *d_h_out, void *stream) {
+    if (!m || !p || !d_traj_rel || !d_losses || !d_h_out) return fail(DAGNET_ERR_INVALID, "null argument");
+    if (p->K != 1) return fail(DAGNET_ERR_INVALID, "forward needs a plan with n_samples == 1");
+    if (T < 1) return fail(DAGNET_ERR_INVALID, "T must be >= 1");
+    if (m->dims.model == DAGNET_MODEL_GRAPH) return fail(DAGNET_ERR_INVALID, "stand-alone graph modules have no forward pass");
+    const bool graph = m->dims.model != DAGNET_MODEL_VRNN;
+    if (m->dims.model == DAGNET_MODEL_DAGNET && (!d_traj || !d_goals)) return fail(DAGNET_ERR_INVALID, "traj and goals are required for DAG-Net");
+    if (int rc = check_plan(m, p)) return rc;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (int rc = plan_enter(p, st, "dagnet_forward")) return rc;      // every path sums the losses in the plan's partials
+    if (int rc = forward_impl(m, p, T, d_traj, d_traj_rel, d_goals, d_adj, adj_dense_ld, d_eps, seed, d_losses, d_h_out, stream)) return rc;
+    // the losses are means over all rows: NaN for a NaN anywhere; h of the row (VRNN) or of the whole batch (graph)
+    const int64_t pl = (int64_t)p->N * 2, hp = (int64_t)p->N * m->dims.R;
+    const DnNanSrc src[2] = {nan_src(d_traj_rel, pl, T, 2), nan_src(graph ? d_traj : nullptr, pl, T, 2)};
+    const DnNanDst dst = graph ? nan_dst(nullptr, 0, 0, 0) : nan_dst(d_h_out, hp, m->dims.L, m->dims.R);
+    HIP_TRY(dn_launch_nan_rows(p->N, src, &dst, d_losses, nullptr, st));
+    if (graph) HIP_TRY(dn_launch_nan_spread(d_losses, 1, d_h_out, 1, 0, hp * m->dims.L, st));
+    return plan_leave(p, st);
 }
 
 extern "C" int dagnet_graph_forward(const dagnet_model *m, const dagnet_plan *p, int32_t which, const float *d_x, const float *d_adj,

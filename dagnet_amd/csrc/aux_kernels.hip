@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include "params.h"
 #include "rng.h"
 
 // one thread per (t, row): writes the row's adjacency to all members of its scene
@@ -114,6 +115,69 @@ __global__ void dn_loss_finalize_kernel(int n_tiles, int N, const double *__rest
         for (int i = 0; i < n_tiles; ++i) t += part[(int64_t)i * 3 + threadIdx.x];
         losses[threadIdx.x] = threadIdx.x < 2 ? t / (double)N : t;
     }
+}
+
+// NaN guard.  The register-resident kernels are built without NaN bookkeeping (csrc/Makefile V2FLAGS) and the other kernels clamp
+// with fmaxf, which drops a NaN operand: a NaN in the inputs could come out as an ordinary number.  The reference's arithmetic
+// gives NaN instead - for the row that holds it, and with a graph for EVERY row of the batch from the next step on (its attention
+// and adjacency products are dense over the block-diagonal batch: 0 * NaN = NaN reaches all scenes).  These two kernels run after
+// the rollout / teacher-forced pass on the same stream, test the INPUTS' bit patterns (integer compares: no floating-point flag
+// folds them away) and overwrite what the reference would have made NaN.
+//   row kernel: one 64-thread workgroup per row; a row with a NaN input gets its `d` region and the `losses` poisoned and,
+//               for graph models, raises `marker` (one word of the output that the spread kernel will overwrite anyway)
+//   spread kernel: if the marker holds a NaN, fills `chunks` pieces of `len` words with NaNs
+__global__ __launch_bounds__(64) void dn_nan_rows_kernel(DnNanSrc s0, DnNanSrc s1, DnNanDst d, uint64_t *__restrict__ losses,
+                                                         uint32_t *__restrict__ marker) {
+    const int64_t r = blockIdx.x;
+    int bad = 0;
+    const DnNanSrc src[2] = {s0, s1};
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        if (!src[i].p) continue;
+        for (int pl = 0; pl < src[i].planes; ++pl) {
+            const uint32_t *q = src[i].p + pl * src[i].plane_stride + r * src[i].cols;
+            for (int j = threadIdx.x; j < src[i].cols; j += 64) bad |= (q[j] & 0x7fffffffu) > 0x7f800000u;
+        }
+    }
+    if (!__syncthreads_or(bad)) return;
+    if (d.p)
+        for (int64_t pl = 0; pl < d.planes; ++pl) {
+            uint32_t *q = d.p + pl * d.plane_stride + r * d.cols;
+            for (int j = threadIdx.x; j < d.cols; j += 64) q[j] = 0x7fc00000u;
+        }
+    if (losses && threadIdx.x < 3) losses[threadIdx.x] = 0x7ff8000000000000ull;
+    if (marker && threadIdx.x == 0) *marker = 0x7fc00000u;
+}
+
+__global__ __launch_bounds__(256) void dn_nan_spread_kernel(const uint32_t *__restrict__ marker, int marker_is_double, uint32_t *base,
+                                                            int chunks, int64_t chunk_stride, int64_t len) {
+    bool bad;
+    if (marker_is_double) {
+        const uint32_t lo = marker[0], hi = marker[1] & 0x7fffffffu;
+        bad = hi > 0x7ff00000u || (hi == 0x7ff00000u && lo != 0);
+    } else {
+        bad = (marker[0] & 0x7fffffffu) > 0x7f800000u;
+    }
+    if (!bad) return;
+    for (int c = 0; c < chunks; ++c)
+        for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < len; j += (int64_t)gridDim.x * 256) base[c * chunk_stride + j] = 0x7fc00000u;
+}
+
+extern "C" hipError_t dn_launch_nan_rows(int64_t rows, const DnNanSrc *src, const DnNanDst *dst, double *losses, void *marker,
+                                         hipStream_t st) {
+    if (rows < 1) return hipSuccess;
+    hipLaunchKernelGGL(dn_nan_rows_kernel, dim3((unsigned)rows), dim3(64), 0, st, src[0], src[1], *dst, reinterpret_cast<uint64_t *>(losses),
+                       static_cast<uint32_t *>(marker));
+    return hipGetLastError();
+}
+
+extern "C" hipError_t dn_launch_nan_spread(const void *marker, int marker_is_double, void *base, int chunks, int64_t chunk_stride,
+                                           int64_t len, hipStream_t st) {
+    if (chunks < 1 || len < 1) return hipSuccess;
+    const int64_t want = (len + 255) / 256;
+    hipLaunchKernelGGL(dn_nan_spread_kernel, dim3((unsigned)(want < 1024 ? want : 1024)), dim3(256), 0, st,
+                       static_cast<const uint32_t *>(marker), marker_is_double, static_cast<uint32_t *>(base), chunks, chunk_stride, len);
+    return hipGetLastError();
 }
 
 // abs[t] = start + cumsum_t(rel)   (models/utils/utils.py:8-21); one thread per row

@@ -126,3 +126,16 @@ struct DnParams {
     DnWeights w;
     DnRun r;
 };
+
+// operands of dn_launch_nan_guard (aux_kernels.hip): 32-bit words, rows `cols` words apart, `planes` leading planes
+struct DnNanSrc {
+    const uint32_t *p;        // NULL = absent
+    int64_t plane_stride;     // words between planes ([L] or [T] leading dimension)
+    int32_t planes, cols;     // rows are `cols` words apart
+};
+struct DnNanDst {
+    uint32_t *p;
+    int64_t plane_stride;
+    int64_t planes;
+    int32_t cols;
+};

@@ -101,7 +101,11 @@ int dagnet_plan_kernel(const dagnet_plan *p);
  *   d_q       [K,T,N,G] injected Exp(1) variates for the goal draw (DAG-Net), or NULL
  *   d_force_goals int32[K,T,N] or NULL: overrides the categorical draw (tests)
  *   d_out     [K,T,N,2] predicted displacements (the reference's `samples`)
- *   d_out_goals int32[K,T,N] or NULL: sampled goal index per step (DAG-Net)            */
+ *   d_out_goals int32[K,T,N] or NULL: sampled goal index per step (DAG-Net)
+ * A NaN in d_h0 comes out as the reference's arithmetic would let it: NaN for that row (VRNN), and with a graph NaN for
+ * the row at step 0 and for the whole batch from step 1 on (the reference's attention / adjacency products are dense over
+ * the block-diagonal batch).  A plan whose sample() works in buffers of the plan (dagnet_plan_kernel() 1 or 3) refuses a
+ * call while an earlier call on ANOTHER stream is still running (DAGNET_ERR_INVALID); calls on one stream are ordered. */
 int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_t T,
                   const float *d_h0, const float *d_x0, const int32_t *d_g0,
                   const float *d_eps, const float *d_q, const int32_t *d_force_goals,
@@ -119,7 +123,10 @@ int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_t T,
  *   d_eps      [T-1,N,Z] injected noise for steps 1..T-1, or NULL -> Philox
  *   d_losses   double[3]: KLD, NLL, CE accumulated as the reference does (mean over rows per
  *              step for KLD/NLL, sum for CE)
- *   d_h_out    [L,N,R]                                                                   */
+ *   d_h_out    [L,N,R]
+ * A NaN in d_traj_rel / d_traj makes the three losses NaN, and d_h_out NaN for the row (VRNN) or the batch (graph models).
+ * The losses are summed in buffers of the plan: a call is refused (DAGNET_ERR_INVALID) while an earlier call on this plan is
+ * still running on another stream - use one plan per stream; calls on one stream are ordered.            */
 int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32_t T,
                    const float *d_traj, const float *d_traj_rel, const int32_t *d_goals,
                    const float *d_adj, int64_t adj_dense_ld, const float *d_eps, uint64_t seed,

@@ -84,12 +84,42 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// in-place softmax over the first G columns of every row; one wave per row
+// in-place softmax over the first G columns of every row; one wave per row.  Rows of up to 1024 columns are read once
+// (float4 pieces held in registers between the three passes).
 __global__ void softmax_kernel(int64_t rows, int G, int64_t ld, float *__restrict__ x) {
     const int64_t r = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (r >= rows) return;
     const int lane = threadIdx.x & 63;
     float *p = x + r * ld;
+    constexpr float LOG2E = 1.4426950408889634f;
+    if ((G & 3) == 0 && (ld & 3) == 0 && G <= 1024) {
+        float4 v[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = lane + 64 * i;
+            v[i] = c4 < (G >> 2) ? *reinterpret_cast<const float4 *>(p + 4 * c4) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            mx = fmaxf(fmaxf(mx, fmaxf(v[i].x, v[i].y)), fmaxf(v[i].z, v[i].w));
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[i].x = __builtin_amdgcn_exp2f((v[i].x - mx) * LOG2E);
+            v[i].y = __builtin_amdgcn_exp2f((v[i].y - mx) * LOG2E);
+            v[i].z = __builtin_amdgcn_exp2f((v[i].z - mx) * LOG2E);
+            v[i].w = __builtin_amdgcn_exp2f((v[i].w - mx) * LOG2E);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        s = wave_sum(s);
+        const float inv = 1.0f / s;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < (G >> 2)) *reinterpret_cast<float4 *>(p + 4 * c4) = make_float4(v[i].x * inv, v[i].y * inv, v[i].z * inv, v[i].w * inv);
+        }
+        return;
+    }
     float mx = -INFINITY;
     for (int c = lane; c < G; c += 64) mx = fmaxf(mx, p[c]);
     mx = wave_max(mx);
@@ -200,8 +230,10 @@ __global__ __launch_bounds__(256) void attn_mix_kernel(int N, int S, const int32
     }
 }
 
-// categorical draw of the goal (utils.py:200-207 via multinomial == argmax p/q, q ~ Exp(1)); one wave per row.
-// The reference feeds exp(softmax probabilities) to multinomial (models/dagnet/model.py:232-233).
+// categorical draw of the goal (utils.py:200-207 via multinomial == argmax w/q, q ~ Exp(1)); one wave per row.
+// The reference feeds w = exp(softmax probabilities) to multinomial (models/dagnet/model.py:232-233).  The race is run in the
+// log domain like the register-resident kernel's (rollout_v2.hip): argmax_c  p_c * log2(e) - log2(q_c), with
+// log2(q) = log2(24 - log2(n)) + const for the in-kernel stream's q = -ln(n / 2^24) - no division, hardware exp2 / log2 only.
 __global__ void draw_kernel(int N, int K, int T, int t, int G, const float *__restrict__ LG, int64_t ld, const float *__restrict__ q,
                             uint64_t seed, const int32_t *__restrict__ force_goals, int32_t *__restrict__ goal,
                             int32_t *__restrict__ out_goals) {
@@ -210,20 +242,61 @@ __global__ void draw_kernel(int N, int K, int T, int t, int G, const float *__re
     const int lane = threadIdx.x & 63;
     const int g = (int)(r % N), k = (int)(r / N);
     const float *p = LG + r * ld;
-    float mx = -INFINITY;
-    for (int c = lane; c < G; c += 64) mx = fmaxf(mx, p[c]);
-    mx = wave_max(mx);
-    float s = 0.f;
-    for (int c = lane; c < G; c += 64) s += expf(p[c] - mx);
-    s = wave_sum(s);
-    const float inv = 1.0f / s;
+    constexpr float LOG2E = 1.4426950408889634f;
     const int64_t slot = ((int64_t)k * T + t) * N + g;
-    float best = -1.f;
+    float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int c = lane; c < G; c += 64) {
-        const float qq = q ? q[slot * G + c] : rng_exp1(seed, (uint32_t)r, (uint32_t)t, (uint32_t)c);
-        const float v = expf(expf(p[c] - mx) * inv) / qq;
-        if (v > best) { best = v; bi = c; }            // c increases: the first maximum of the lane wins
+    if (!q && (G & 3) == 0 && (ld & 3) == 0 && G <= 1024) {
+        // in-kernel stream: columns 4c..4c+3 are the four words of ONE Philox block (rng.h rng_bits: counter j >> 2, word j & 3),
+        // so a lane takes four consecutive columns per block; its (at most 4) float4 pieces of the row stay in registers
+        float4 x[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = lane + 64 * i;
+            x[i] = c4 < (G >> 2) ? *reinterpret_cast<const float4 *>(p + 4 * c4) : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            mx = fmaxf(fmaxf(mx, fmaxf(x[i].x, x[i].y)), fmaxf(x[i].z, x[i].w));
+        }
+        mx = wave_max(mx);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            x[i].x = __builtin_amdgcn_exp2f((x[i].x - mx) * LOG2E);
+            x[i].y = __builtin_amdgcn_exp2f((x[i].y - mx) * LOG2E);
+            x[i].z = __builtin_amdgcn_exp2f((x[i].z - mx) * LOG2E);
+            x[i].w = __builtin_amdgcn_exp2f((x[i].w - mx) * LOG2E);
+            s += (x[i].x + x[i].y) + (x[i].z + x[i].w);
+        }
+        s = wave_sum(s);
+        const float pscale = LOG2E / s;
+        const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 >= (G >> 2)) break;
+            const uint4 rb = philox4x32(make_uint4((uint32_t)r, (uint32_t)t, (uint32_t)c4, 1u), key);
+            const float xs[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+            const uint32_t bs[4] = {rb.x, rb.y, rb.z, rb.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float n = (float)(bs[e] >> 8) + 1.0f;                     // q = -ln(n / 2^24)
+                const float v = xs[e] * pscale - __builtin_amdgcn_logf(24.0f - __builtin_amdgcn_logf(n));
+                if (v > best) { best = v; bi = 4 * c4 + e; }                    // columns increase: the first maximum wins
+            }
+        }
+    } else {
+        float mx = -INFINITY;
+        for (int c = lane; c < G; c += 64) mx = fmaxf(mx, p[c]);
+        mx = wave_max(mx);
+        float s = 0.f;
+        for (int c = lane; c < G; c += 64) s += __builtin_amdgcn_exp2f((p[c] - mx) * LOG2E);
+        s = wave_sum(s);
+        const float pscale = LOG2E / s;
+        for (int c = lane; c < G; c += 64) {
+            const float qq = q ? q[slot * G + c] : rng_exp1(seed, (uint32_t)r, (uint32_t)t, (uint32_t)c);
+            const float v = __builtin_amdgcn_exp2f((p[c] - mx) * LOG2E) * pscale - __builtin_amdgcn_logf(qq);
+            if (v > best) { best = v; bi = c; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -1,0 +1,4 @@
+set -e
+mkdir -p gpurun_out/r2k
+timeout -k 10 300 python -u -m pytest tests/test_gpu_properties.py tests/test_gpu_parity.py -x -q -k "wide or g960 or sdd" --timeout 120 --timeout-method thread > gpurun_out/r2k/t.log 2>&1 && \
+timeout -k 10 300 python bench.py --workload dagnet_sdd_4096x20 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r2k/sdd.log 2>&1

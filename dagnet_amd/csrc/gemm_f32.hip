@@ -193,6 +193,196 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const NtArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 128 x 128 tiles, software-pipelined variant for the wide layers (N > 96, K a multiple of 32, float4-aligned operands,
+// W[N, K]): the layer that dominates the SDD-shaped goal head (1920 -> 960 over K * N rows).
+//
+// Same tile, LDS layout and MFMA order as gemm_nt_kernel<2, 2, 2, 2>, but the staging around the MFMAs is branch-free and
+// ordered so that one wave keeps the MFMA pipe busy by itself:
+//   * raw buffer loads (one descriptor per operand and tile, 32-bit per-lane offset fixed for the whole kernel, the k position in
+//     the scalar offset): no address arithmetic and no bounds branches per load - rows past the end of the matrix are cut off
+//     by the descriptor's range check and read as 0;
+//   * chunk q + 1 (loaded during chunk q - 1, long since landed) is written to the other LDS buffer and chunk q + 2 is requested
+//     at the TOP of chunk q, in front of its 64 MFMAs; the operand fragments of k-group j + 1 are read while group j multiplies.
+//     What is left exposed per chunk is one barrier.
+// (The previous kernel issued its loads under 16 exec-masked branches, which also kept the compiler from moving anything across
+// them; two workgroups per CU then ran in convoy - both loading, both multiplying - at 0.72 of the fp32 MFMA peak.)
+// ---------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ f32x4 gp_load4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ void gp_store1(float data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+
+__device__ __forceinline__ i32x4 gp_rsrc(const float *base, int64_t bytes) {
+    union { const float *p; int w[2]; } u;
+    u.p = base;
+    const int64_t lim = bytes < 0 ? 0 : (bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes);
+    return i32x4{__builtin_amdgcn_readfirstlane(u.w[0]), __builtin_amdgcn_readfirstlane(u.w[1]), __builtin_amdgcn_readfirstlane((int)lim),
+                 0x00020000};
+}
+
+// BKP: k-chunk (32 or 16), WPC: workgroups per CU the registers are budgeted for (LDS: 2 * 256 * (BKP + 4) * 4 bytes each)
+template <int BKP, int WPC>
+__global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) {
+    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+    constexpr int LDP = BKP + 4;                 // LDS row stride (floats): 16 rows x 16 B cover the 64 banks once for 36 and for 20
+    constexpr int TPR = BKP / 4, RPP = 256 / TPR, NL = 128 / RPP;      // loader: threads per row, rows per pass, passes
+    extern __shared__ float smem[];
+    float *sA = smem;                       // [2][BM][LDP]
+    float *sB = smem + 2 * BM * LDP;        // [2][BN][LDP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int nbn = (p.N + BN - 1) / BN;
+    const int64_t total = (int64_t)((p.M + BM - 1) / BM) * nbn, per_xcd = (total + 7) / 8;
+    const int64_t xbeg = (int64_t)(blockIdx.x & 7) * per_xcd, xend = min(xbeg + per_xcd, total);
+    const int64_t tstride = gridDim.x >> 3;
+    int64_t tile = xbeg + (blockIdx.x >> 3);
+    if (tile >= xend) return;
+    const int nk = p.K / BKP;
+
+    // loader: this thread's float4 of row tid / TPR + RPP i, k columns 4 (tid % TPR) .. + 3 of a chunk
+    const int lrow = tid / TPR, lc4 = (tid % TPR) * 4;
+    const int lda4 = (int)p.lda * 4, ldw4 = (int)p.ldw * 4;
+    const int voa = lrow * lda4 + lc4 * 4, vow = lrow * ldw4 + lc4 * 4;
+    f32x4 ga[NL], gb[NL];
+    int64_t ltile = tile;       // tile and chunk the loader is at
+    int lkc = 0;
+    i32x4 ra, rw;
+    auto set_desc = [&](int64_t t) {
+        if (t < xend) {
+            const int m0 = (int)(t / nbn) * BM, n0 = (int)(t % nbn) * BN;
+            ra = gp_rsrc(p.A + (int64_t)m0 * p.lda, (int64_t)(p.M - m0) * lda4);
+            rw = gp_rsrc(p.W + (int64_t)n0 * p.ldw, (int64_t)(p.N - n0) * ldw4);
+        } else {                // past this workgroup's last tile: empty buffers, every load returns 0 without touching memory
+            ra = gp_rsrc(p.A, 0);
+            rw = gp_rsrc(p.W, 0);
+        }
+    };
+    auto gload = [&]() {        // request the loader's chunk, then step the loader
+        const int so = lkc * (BKP * 4);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) ga[i] = gp_load4(ra, voa + i * RPP * lda4, so, 0);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) gb[i] = gp_load4(rw, vow + i * RPP * ldw4, so, 0);
+        if (++lkc == nk) {
+            lkc = 0;
+            ltile += tstride;
+            set_desc(ltile);
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4 *>(sA + (buf * BM + lrow + RPP * i) * LDP + lc4) = ga[i];
+#pragma unroll
+        for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4 *>(sB + (buf * BN + lrow + RPP * i) * LDP + lc4) = gb[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    set_desc(ltile);
+    gload();
+    sstore(0);
+    gload();                    // chunk 1 (or the next tile's chunk 0, or zeros) waits in registers
+    __syncthreads();
+    int buf = 0, kc = 0;
+    int m0 = (int)(tile / nbn) * BM, n0 = (int)(tile % nbn) * BN;
+    while (true) {
+        sstore(buf ^ 1);        // chunk q + 1 -> the buffer that chunk q - 1 was read from (all waves passed the barrier since)
+        gload();                // chunk q + 2
+        const float *a_base = sA + (buf * BM + (wm * TM) * 32 + lr) * LDP + 4 * lh;
+        const float *b_base = sB + (buf * BN + (wn * TN) * 32 + lr) * LDP + 4 * lh;
+        f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) fa[0][a] = *reinterpret_cast<const f32x4 *>(a_base + a * 32 * LDP);
+#pragma unroll
+        for (int b = 0; b < TN; ++b) fb[0][b] = *reinterpret_cast<const f32x4 *>(b_base + b * 32 * LDP);
+#pragma unroll
+        for (int j = 0; j < BKP / 8; ++j) {
+            if (j < BKP / 8 - 1) {
+#pragma unroll
+                for (int a = 0; a < TM; ++a) fa[(j + 1) & 1][a] = *reinterpret_cast<const f32x4 *>(a_base + a * 32 * LDP + 8 * (j + 1));
+#pragma unroll
+                for (int b = 0; b < TN; ++b) fb[(j + 1) & 1][b] = *reinterpret_cast<const f32x4 *>(b_base + b * 32 * LDP + 8 * (j + 1));
+            }
+            // keep the reads of group j + 1 in FRONT of group j's 16 MFMAs (left alone, the scheduler sinks them to two MFMAs
+            // before their use and the wave then waits out the LDS latency in every group)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][a][i], fb[j & 1][b][i], acc[a][b], 0, 0, 0);
+        }
+        if (++kc == nk) {
+            // epilogue: lane = output column, register r <-> row (r&3) + 8(r>>2) + 4h of the 32x32 tile
+            if (!p.gather && !p.accumulate) {
+                // plain layer: one buffer descriptor per 32-row slab, the row and column of an element in the 32-bit offset
+                // (rows past M and columns past N fall outside the descriptor's range: dropped by the hardware), one
+                // v_add per address; tanh through exp2 / rcp (absolute error ~1e-7)
+                const int ldc4 = (int)p.ldc * 4;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int row0 = m0 + (wm * TM + a) * 32;
+                    const i32x4 rc = gp_rsrc(p.C + (int64_t)row0 * p.ldc, (int64_t)(p.M - row0) * ldc4);
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) {
+                        const int col = n0 + (wn * TN + b) * 32 + lr;
+                        const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+                        const int vo = col < p.N ? 4 * lh * ldc4 + col * 4 : (int)0x80000000u;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = acc[a][b][r] + bv;
+                            if (p.act == ACT_LRELU) v = fmaxf(v, v * p.slope);
+                            else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
+                            else if (p.act == ACT_TANH)
+                                v = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * 2.8853900817779268f));
+                            gp_store1(v, rc, vo + ((r & 3) + 8 * (r >> 2)) * ldc4, 0, 0);
+                            acc[a][b][r] = 0.f;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int col = n0 + (wn * TN + b) * 32 + lr;
+                const float bv = (p.bias && col < p.N) ? p.bias[col] : 0.f;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int rbase = m0 + (wm * TM + a) * 32 + 4 * lh;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = rbase + (r & 3) + 8 * (r >> 2);
+                        if (row < p.M && col < p.N) {
+                            float v = acc[a][b][r] + bv;
+                            if (p.gather) v += p.gather[(int64_t)p.gidx[row] * p.gs_g + (int64_t)col * p.gs_n];
+                            float *dst = p.C + (int64_t)row * p.ldc + col;
+                            if (p.accumulate) v += *dst;
+                            *dst = act_apply(p.act, v, p.slope);
+                        }
+                        acc[a][b][r] = 0.f;
+                    }
+                }
+            }
+            }
+            kc = 0;
+            tile += tstride;
+            if (tile >= xend) break;
+            m0 = (int)(tile / nbn) * BM;
+            n0 = (int)(tile % nbn) * BN;
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 struct TnArgs {
     const float *A; int64_t lda;      // [M, N]  (e.g. dY)
     const float *B; int64_t ldb;      // [M, K]  (e.g. X)
@@ -342,6 +532,22 @@ static hipError_t launch_nt_cfg(const NtArgs &a, bool veca, bool vecb, bool tran
     return hipErrorInvalidValue;
 }
 
+static hipError_t launch_nt_pipe(const NtArgs &a, hipStream_t st) {
+    constexpr int BM = 128, BN = 128;
+    const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    static const int variant = getenv("DAGNET_PIPE_VARIANT") ? atoi(getenv("DAGNET_PIPE_VARIANT")) : 0;
+    if (variant == 1 && a.K % 16 == 0) {
+        const size_t lds = (size_t)2 * (BM + BN) * 20 * sizeof(float);
+        const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, 256 * 3);
+        hipLaunchKernelGGL((gemm_nt_pipe_kernel<16, 3>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    } else {
+        const size_t lds = (size_t)2 * (BM + BN) * LDT * sizeof(float);
+        const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, 256 * 2);
+        hipLaunchKernelGGL((gemm_nt_pipe_kernel<32, 2>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    }
+    return hipGetLastError();
+}
+
 }  // namespace gemm
 
 // General entry: C = act([C +] A op(B) + bias + gather), op(B) = W[N,K]^T (transb = 0) or B[K,N] (transb = 1).
@@ -367,7 +573,13 @@ extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64
     const bool vecb = !((ldb & 3) || ((transb ? N : K) & 3) || (reinterpret_cast<uintptr_t>(B) & 15));
     gemm::NtArgs a{A, lda, B, ldb, bias, C, ldc, M, N, K, slope, gather, gidx, gs_g, gs_n, act, accumulate};
     if (N > 128 && N <= 192) return gemm::launch_nt_cfg<2, 2, 1, 3>(a, veca, vecb, transb != 0, st);   // 64 x 192: the GRU gate columns in one tile, A read once
-    if (N > 96) return gemm::launch_nt_cfg<2, 2, 2, 2>(a, veca, vecb, transb != 0, st);     // 128 x 128
+    if (N > 96) {                                                                             // 128 x 128
+        static const bool no_pipe = getenv("DAGNET_NO_PIPE") != nullptr;
+        if (!no_pipe && veca && vecb && !transb && K % gemm::BK == 0 && lda * 4 * 128 < 0x7fffffffLL && ldb * 4 * 128 < 0x7fffffffLL &&
+            ldc * 4 * 128 < 0x7fffffffLL)
+            return gemm::launch_nt_pipe(a, st);
+        return gemm::launch_nt_cfg<2, 2, 2, 2>(a, veca, vecb, transb != 0, st);
+    }
     // 128 x 96: g_dim = 90 in one column tile
     if (N > 64) return gemm::launch_nt_cfg<4, 1, 1, 3>(a, veca, vecb, transb != 0, st);
     if (N > 32) return gemm::launch_nt_cfg<2, 2, 1, 1>(a, veca, vecb, transb != 0, st);     // 64 x 64 (measured: 7 % of a training step over 128 x 64)

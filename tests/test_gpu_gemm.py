@@ -1,5 +1,6 @@
 """GPU: dagnet_op_gemm on the tall-and-skinny shapes of the training step (csrc/gemm_skinny.hip takes M >= 2048, N <= 192, K <= 96
-with 16-byte rows; everything else the LDS-tiled kernel of csrc/gemm_f32.hip) against torch's fp32 matmul: every epilogue
+with 16-byte rows; wide outputs with K a multiple of 32 the software-pipelined 128 x 128 kernel; everything else the LDS-tiled
+kernel of csrc/gemm_f32.hip) against torch's fp32 matmul: every epilogue
 (bias, one-hot gather, activation, accumulate), both operand orders, padded row strides, K and N that are not multiples
 of 4 or 32, a row count that is not a multiple of 32."""
 import pytest
@@ -21,7 +22,7 @@ def _padded(M, N, gen, nan_pad=True):
 
 @pytest.mark.parametrize("M,N,K", [(4096, 64, 64), (5000, 90, 64), (2049, 64, 90), (3000, 192, 64), (2100, 32, 20), (2500, 90, 90),
                                    (2048, 2, 64), (2300, 64, 2), (4000, 64, 32), (1000, 64, 64), (4100, 64, 192), (2200, 90, 180),
-                                   (2500, 20, 130), (2100, 128, 192)])
+                                   (2500, 20, 130), (2100, 128, 192), (3000, 960, 64), (2500, 250, 32), (1500, 300, 96), (700, 200, 1920)])
 @pytest.mark.parametrize("transb", [False, True])
 def test_gemm_matches_torch(M, N, K, transb):
     g = torch.Generator().manual_seed(M + N + K)
@@ -38,6 +39,10 @@ def test_gemm_matches_torch(M, N, K, transb):
     C = _padded(M, N, g)
     _ops.gemm(A, W, C, transb=transb, bias=bias, act=_ops.ACT_LRELU, slope=0.01)
     torch.testing.assert_close(C.double(), torch.nn.functional.leaky_relu(ref + bias.double(), 0.01), **tol)
+    # bias + tanh (the pipelined 128 x 128 kernel's fast epilogue computes it through exp2 / rcp)
+    C = _padded(M, N, g)
+    _ops.gemm(A, W, C, transb=transb, bias=bias, act=_ops.ACT_TANH)
+    torch.testing.assert_close(C.double(), torch.tanh(ref + bias.double()), **tol)
     # accumulate into existing values, tanh
     C0 = torch.randn((M, N), generator=g).to(DEV)
     C = _padded(M, N, g)

@@ -583,7 +583,6 @@ bool v2_eligible(const dagnet_config &c) {
     if (c.model != DAGNET_MODEL_VRNN) {
         if (c.graph_model == DAGNET_GRAPH_GAT && (c.n_heads != 4 || c.graph_hid != 8)) return false;
         if (c.graph_model == DAGNET_GRAPH_GCN && c.graph_hid > 32) return false;
-        if (c.adjacency_type != 0 && c.adjacency_type != 1) return false;
     }
     if (c.model == DAGNET_MODEL_DAGNET && (c.g_dim > 96 || c.n_max_agents > 32)) return false;
     if (c.model == DAGNET_MODEL_DAGNET && c.n_max_agents > 16 && !dn_v2_has(4, c.n_layers, c.z_dim, c.graph_model)) return false;
@@ -598,7 +597,6 @@ bool wide_eligible(const dagnet_config &c) {
     if (c.x_dim != 2 || c.h_dim != 64 || c.rnn_dim != 64) return false;
     if (!dn_v2_has(3, c.n_layers, c.z_dim, DAGNET_GRAPH_GAT)) return false;
     if (c.graph_model != DAGNET_GRAPH_GAT || c.n_heads != 4 || c.graph_hid != 8) return false;
-    if (c.adjacency_type != 0 && c.adjacency_type != 1) return false;
     if (c.g_dim <= 96 || (c.g_dim & 3) || c.n_max_agents > 32) return false;
     return true;
 }
@@ -1214,7 +1212,7 @@ static int sample_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, c
         r.wp = m->d_wp + m->v2_base;      // rollout_v2: compile-time offsets relative to the v2 region
         r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
         r.S = p->S; r.N = p->N; r.K = p->K; r.T = T; r.n_tiles = p->n_tiles2;
-        r.G = m->dims.G; r.D = m->dims.D; r.adj_type = m->dims.adj_type;
+        r.G = m->dims.G; r.D = m->dims.D; r.adj_type = m->dims.adj_type; r.top_k = m->dims.knn_k;
         r.alpha = m->dims.alpha; r.sigma = m->dims.sigma;
         r.h0 = d_h0; r.x0 = d_x0; r.g0 = d_g0; r.eps = d_eps; r.q = d_q; r.force_goals = d_force_goals;
         r.seed = seed; r.out = d_out; r.out_goals = d_out_goals;
@@ -1244,7 +1242,7 @@ static int sample_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, c
         r.wp = m->d_wp;                    // model 3: absolute offsets from the table
         r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
         r.S = p->S; r.N = p->N; r.K = p->K; r.T = T; r.n_tiles = p->n_tiles2;
-        r.G = D.G; r.D = D.D; r.adj_type = D.adj_type; r.alpha = D.alpha; r.sigma = D.sigma;
+        r.G = D.G; r.D = D.D; r.adj_type = D.adj_type; r.top_k = D.knn_k; r.alpha = D.alpha; r.sigma = D.sigma;
         r.h0 = p->wb.h; r.x0 = p->wb.pos; r.g0 = p->wb.goal; r.eps = d_eps; r.seed = seed; r.out = d_out;
         r.h_out = p->wb.h; r.x_out = p->wb.pos;
         for (int t = 0; t < T; ++t) {
@@ -1344,7 +1342,7 @@ static int forward_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, 
         r.wp = m->d_wp;
         r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
         r.S = p->S; r.N = p->N; r.K = 1; r.T = T; r.n_tiles = p->n_tiles2;
-        r.G = D.G; r.D = D.D; r.adj_type = D.adj_type; r.alpha = D.alpha; r.sigma = D.sigma;
+        r.G = D.G; r.D = D.D; r.adj_type = D.adj_type; r.top_k = D.knn_k; r.alpha = D.alpha; r.sigma = D.sigma;
         r.eps = d_eps; r.seed = seed; r.h_out = d_h_out;
         r.traj = d_traj; r.traj_rel = d_traj_rel; r.goals = d_goals;
         r.adj = P.r.adj; r.adj_ld = P.r.adj_ld; r.adj_tstride = P.r.adj_tstride; r.adj_off = P.r.adj_off;
@@ -1370,7 +1368,7 @@ static int forward_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, 
         r.wp = m->d_wp + m->v2_base;      // compile-time offsets relative to the v2 region
         r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
         r.S = p->S; r.N = p->N; r.K = 1; r.T = T; r.n_tiles = p->n_tiles2;
-        r.G = m->dims.G; r.D = m->dims.D; r.adj_type = m->dims.adj_type; r.alpha = m->dims.alpha; r.sigma = m->dims.sigma;
+        r.G = m->dims.G; r.D = m->dims.D; r.adj_type = m->dims.adj_type; r.top_k = m->dims.knn_k; r.alpha = m->dims.alpha; r.sigma = m->dims.sigma;
         r.eps = d_eps; r.seed = seed; r.h_out = d_h_out;
         r.traj = d_traj; r.traj_rel = d_traj_rel; r.goals = d_goals;
         r.adj = P.r.adj; r.adj_ld = P.r.adj_ld; r.adj_tstride = P.r.adj_tstride; r.adj_off = P.r.adj_off;

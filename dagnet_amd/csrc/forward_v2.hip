@@ -367,7 +367,9 @@ static hipError_t launch_fwd(const V2Weights *d_w, const V2Run &r, hipStream_t s
 
 #define V2F_INSTANCES                                                                                                  \
     V2_CASE(2, 2, 32, 1) V2_CASE(1, 1, 32, 1) V2_CASE(0, 2, 32, 1) V2_CASE(1, 1, 16, 1) V2_CASE(0, 2, 16, 1) V2_CASE(1, 2, 32, 1) \
-    V2_CASE(3, 2, 32, 1) V2_CASE(4, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2)
+    V2_CASE(3, 2, 32, 1) V2_CASE(4, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2) \
+    V2_CASE(2, 1, 32, 1) V2_CASE(2, 2, 16, 1) V2_CASE(4, 1, 32, 1) V2_CASE(4, 2, 16, 1) V2_CASE(3, 1, 32, 1) V2_CASE(3, 2, 16, 1) \
+    V2_CASE(2, 1, 32, 2) V2_CASE(2, 2, 16, 2)
 
 extern "C" hipError_t dn_launch_forward_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *d_w, const V2Run *r,
                                            hipStream_t st) {

@@ -150,6 +150,7 @@ struct V2Run {
     const int32_t *scene_ptr, *tile_u0, *tile_nu;
     int32_t S, N, K, T, n_tiles;
     int32_t G, D, adj_type;
+    int32_t top_k;                   // kNN adjacency (adj_type 2): neighbours kept per row
     float alpha;
     double sigma;
     const float *h0, *x0;

@@ -155,6 +155,47 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             if (lh == 0) { pos[lc * 2] = xa; pos[lc * 2 + 1] = ya; }
             __syncthreads();
             unsigned mk = 0;
+            if (R.adj_type == 2) {
+                // kNN (adjacency_matrix.py:86-103): column j is on iff it is among the min(top_k, n) nearest of this row, the row
+                // itself included; ranked by the squared distance in fp64, ties by index - the order of the other kernels
+                // (aux_kernels.hip dn_adjacency_kernel, rollout_body.h).  The two lanes of a row hold 16 candidates each: pass p
+                // finds the p-th smallest key (d2, j) of the 32 - each half the smallest of its own that is greater than the
+                // previous one, then the smaller of the two halves' - and the last one found is the threshold.
+                double dq[16];
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = FR(r) + 4 * lh;
+                    const float2 pj = *reinterpret_cast<const float2 *>(pos + j * 2);
+                    const double dx = (double)xa - (double)pj.x, dy = (double)ya - (double)pj.y;
+                    dq[r] = ((j >= s0) & (j < s0 + n)) ? dx * dx + dy * dy : (double)INFINITY;
+                }
+                const int kk = min(R.top_k, n);
+                double pd = -1.0;
+                int pj = -1;
+                for (int p = 0; p < R.top_k && p < 32; ++p) {
+                    double cd = (double)INFINITY;
+                    int cj = 64;
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = FR(r) + 4 * lh;
+                        const bool gt = (dq[r] > pd) | ((dq[r] == pd) & (j > pj));
+                        const bool lt = (dq[r] < cd) | ((dq[r] == cd) & (j < cj));
+                        if (gt & lt) { cd = dq[r]; cj = j; }
+                    }
+                    const double od = __shfl_xor(cd, 32);
+                    const int oj = __shfl_xor(cj, 32);
+                    if ((od < cd) | ((od == cd) & (oj < cj))) { cd = od; cj = oj; }
+                    if (p < kk) { pd = cd; pj = cj; }       // a scene smaller than top_k has all its columns on after n passes
+                }
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = FR(r) + 4 * lh;
+                    const bool on = (j >= s0) & (j < s0 + n) & ((dq[r] < pd) | ((dq[r] == pd) & (j <= pj)));
+                    mk |= on ? (1u << r) : 0u;
+                }
+                amask = mk;
+                return;
+            }
             const double lim = 103.97207708399179 * R.sigma, lim2 = lim * lim;      // 150 ln 2 = 103.972077...
             const bool nodist = R.adj_type != 1;
     #pragma unroll
@@ -175,6 +216,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             const int j = FR(r) + 4 * lh;
             const bool in = (j >= s0) & (j < s0 + n);
             float v = 1.0f;
+            if (R.adj_type == 2) return (amask >> r) & 1u ? 1.0f : 0.f;        // kNN: build_mask() holds the row's 0 / 1 entries
             if (R.adj_type == 1) {
                 const float2 pj = *reinterpret_cast<const float2 *>(pos + j * 2);
                 const double dx = (double)xa - (double)pj.x, dy = (double)ya - (double)pj.y;
@@ -479,11 +521,13 @@ static hipError_t launch_one(const V2Weights *d_w, const V2Run &r, hipStream_t s
 }
 
 // (model, GRU layers, z_dim, graph) combinations with an instantiation: the shapes of the shipped checkpoints
-// (basketball: DAG-Net L2/Z32, A-VRNN L1/Z32, VRNN L2/Z32; SDD: A-VRNN L1/Z16, VRNN L2/Z16) plus A-VRNN L2/Z32, model 3
+// (basketball: DAG-Net L2/Z32, A-VRNN L1/Z32, VRNN L2/Z32; SDD: A-VRNN L1/Z16, VRNN L2/Z16) plus A-VRNN L2/Z32, DAG-Net L1/Z32 and L2/Z16, model 3
 // (goal head outside) and the GCN variants of the graph models.  graph: 0 none (VRNN), 1 GAT, 2 GCN.
 #define V2_INSTANCES                                                                                                   \
     V2_CASE(2, 2, 32, 1) V2_CASE(1, 1, 32, 1) V2_CASE(0, 2, 32, 1) V2_CASE(1, 1, 16, 1) V2_CASE(0, 2, 16, 1) V2_CASE(1, 2, 32, 1) \
-    V2_CASE(3, 2, 32, 1) V2_CASE(4, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2)
+    V2_CASE(3, 2, 32, 1) V2_CASE(4, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2) \
+    V2_CASE(2, 1, 32, 1) V2_CASE(2, 2, 16, 1) V2_CASE(4, 1, 32, 1) V2_CASE(4, 2, 16, 1) V2_CASE(3, 1, 32, 1) V2_CASE(3, 2, 16, 1) \
+    V2_CASE(2, 1, 32, 2) V2_CASE(2, 2, 16, 2)
 
 // returns hipErrorInvalidValue when the combination has no instantiation; d_w: DEVICE pointer to the model's V2Weights table
 extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *d_w, const V2Run *r,

@@ -45,8 +45,16 @@ class generic_kernel:
         del os.environ["DAGNET_FORCE_GENERIC"]
 
 
+KNN = dict(adjacency_type=2, top_k_neigh=3)
+
+
 @pytest.mark.parametrize("kind,kw", [("vrnn", dict(n_layers=2)), ("avrnn", dict(n_layers=1)), ("dagnet", dict(n_layers=2)),
-                                     ("avrnn", dict(n_layers=1, graph_model="gcn")), ("dagnet", dict(n_layers=2, graph_model="gcn"))])
+                                     ("avrnn", dict(n_layers=1, graph_model="gcn")), ("dagnet", dict(n_layers=2, graph_model="gcn")),
+                                     ("avrnn", dict(n_layers=1, **KNN)), ("dagnet", dict(n_layers=2, **KNN)),
+                                     ("avrnn", dict(n_layers=1, graph_model="gcn", **KNN)),
+                                     ("dagnet", dict(n_layers=2, adjacency_type=2, top_k_neigh=12)),     # top_k above the scene size
+                                     ("dagnet", dict(n_layers=1)), ("dagnet", dict(n_layers=2, z_dim=16)),
+                                     ("dagnet", dict(n_layers=1, graph_model="gcn")), ("dagnet", dict(n_layers=2, z_dim=16, graph_model="gcn"))])
 def test_both_kernels_agree_and_are_deterministic(kind, kw):
     """Same seed -> the register-resident and the generic kernel draw the same Philox numbers; trajectories agree to
     fp32 reordering noise, goal indices exactly; a second launch is bitwise identical; another seed differs."""
@@ -54,6 +62,8 @@ def test_both_kernels_agree_and_are_deterministic(kind, kw):
     sizes = [10] * 37
     batch = [t.to(DEV) for t in syn.make_batch(sizes, 10, 40, 3)]
     h = (syn.uniform_noise(3, "h0", (a.n_layers, 370, 64)) - 0.5).to(DEV)
+    sp = syn.scene_ptr(sizes) if kind != "vrnn" else np.arange(371, dtype=np.int32)
+    assert "register-resident" in m.hip_plan(DEV, sp, 4).info()["sample_kernel"]
     extra = dict(return_goals=True) if kind == "dagnet" else {}
     r1 = _sample_k(kind, m, 4, 40, h, batch, seed=11, **extra)
     r2 = _sample_k(kind, m, 4, 40, h, batch, seed=11, **extra)
@@ -67,7 +77,16 @@ def test_both_kernels_agree_and_are_deterministic(kind, kw):
         assert agree > 0.999, f"goal draws of the two kernels agree on only {agree:.4f} of the rows"
         same = (q1 == gq1).all(dim=1)                      # [K,N]: rows whose whole goal sequence agrees
         d = (r1 - g1).abs().amax(dim=(1, 3))
-        assert d[same].max().item() < 1e-3                 # chaotic amplification over 40 steps of ~1e-6 noise
+        if kw.get("adjacency_type") == 2:                  # see below: a flipped near-tie of the kNN ranking
+            assert (d[same] > 1e-3).float().mean().item() < 0.02
+        else:
+            assert d[same].max().item() < 1e-3             # chaotic amplification over 40 steps of ~1e-6 noise
+    elif kw.get("adjacency_type") == 2:
+        # the unnormalised 0/1 kNN adjacency makes the random-weight GCN rollout chaotic (measured: the median difference of the
+        # two kernels grows 2.5x every 5 steps, from 7e-9 at step 0 to 9e-6 at step 35; with GAT it stays at 7e-9): compare the
+        # first 20 steps strictly and only bound the rest
+        d = (r1 - g1).abs().amax(dim=3)
+        assert d[:, :20].max().item() < 2e-4 and d.median().item() < 1e-4
     else:
         assert (r1 - g1).abs().max().item() < 2e-4
     assert torch.equal(r1, r2)
@@ -75,12 +94,16 @@ def test_both_kernels_agree_and_are_deterministic(kind, kw):
     assert torch.isfinite(r1).all()
 
 
-@pytest.mark.parametrize("kind", ["vrnn", "avrnn", "dagnet"])
+@pytest.mark.parametrize("kind", ["vrnn", "avrnn", "dagnet", "avrnn_knn", "dagnet_knn", "dagnet_L1", "dagnet_Z16"])
 @pytest.mark.parametrize("force_generic", [False, True])
 def test_matches_oracle_on_larger_ragged_batch(kind, force_generic):
     """48 ragged scenes (1..32 agents), injected noise, goals forced to the oracle's draws so that the continuous
-    path is compared row by row; the categorical draw itself is compared where its top-2 margin is safe."""
-    kw = dict(vrnn=dict(n_layers=2), avrnn=dict(n_layers=1), dagnet=dict(n_layers=2))[kind]
+    path is compared row by row; the categorical draw itself is compared where its top-2 margin is safe.
+    The *_knn cases run the kNN adjacency (3 neighbours, scenes of 1 and 2 agents included), dagnet_L1 / dagnet_Z16 the
+    other DAG-Net shapes the register-resident kernel is instantiated for."""
+    kw = dict(vrnn=dict(n_layers=2), avrnn=dict(n_layers=1), dagnet=dict(n_layers=2), avrnn_knn=dict(n_layers=1, **KNN),
+              dagnet_knn=dict(n_layers=2, **KNN), dagnet_L1=dict(n_layers=1), dagnet_Z16=dict(n_layers=2, z_dim=16))[kind]
+    kind = kind.split("_")[0]
     sizes = [1, 32, 2, 17] + list(syn.ragged_sizes(44, seed=5, n_max=16))
     nmax = max(sizes)
     a, m, sd = _model(kind, n_max=16 if kind == "dagnet" and nmax <= 16 else nmax, **kw)
@@ -91,7 +114,8 @@ def test_matches_oracle_on_larger_ragged_batch(kind, force_generic):
     h = syn.uniform_noise(seed, "h0", (a.n_layers, N, 64)) - 0.5
     eps = syn.uniform_noise(seed, "eps", (K, T, N, a.z_dim))
     q = syn.exp1_noise(seed, "q", (K, T, N, a.g_dim))
-    cfg = orc.make_cfg(n_max_agents=m.n_max_agents if kind == "dagnet" else nmax, n_layers=a.n_layers)
+    cfg = orc.make_cfg(n_max_agents=m.n_max_agents if kind == "dagnet" else nmax, n_layers=a.n_layers, z_dim=a.z_dim,
+                       adjacency_type=a.adjacency_type, top_k_neigh=a.top_k_neigh)
     want, wgoals, margins = [], [], []
     with torch.no_grad():
         for k in range(K):
@@ -274,12 +298,13 @@ def test_kernel_dispatch(name, want):
     assert want in model.hip_plan(DEV, sp, meta["K"]).info()["sample_kernel"]
 
 
-def test_wide_goal_head_agrees_with_generic_kernel_on_ragged_sdd_batch():
+@pytest.mark.parametrize("adj_kw", [{}, KNN], ids=["distsim", "knn"])
+def test_wide_goal_head_agrees_with_generic_kernel_on_ragged_sdd_batch(adj_kw):
     """g_dim = 960 (SDD-shaped DAG-Net), 60 ragged scenes of 2..32 agents, K = 3: the layer-by-layer wide goal head +
     register-resident step kernel against the generic kernel with goal buffers in global scratch.  With injected noise the
     drawn goals are identical wherever the draw is not a near-tie and the trajectories agree to fp32 reordering noise;
     with the in-kernel Philox stream both paths draw the same numbers."""
-    a, m, _ = _model("dagnet", n_max=32, seed=9, n_layers=2, g_dim=960)
+    a, m, _ = _model("dagnet", n_max=32, seed=9, n_layers=2, g_dim=960, **adj_kw)
     sizes = [int(v) for v in syn.ragged_sizes(60, seed=4)]
     assert max(sizes) <= 32 and min(sizes) >= 2
     N, K, T = sum(sizes), 3, 6

@@ -161,36 +161,42 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
                 // (aux_kernels.hip dn_adjacency_kernel, rollout_body.h).  The two lanes of a row hold 16 candidates each: pass p
                 // finds the p-th smallest key (d2, j) of the 32 - each half the smallest of its own that is greater than the
                 // previous one, then the smaller of the two halves' - and the last one found is the threshold.
-                double dq[16];
-    #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                // (the squared distances are recomputed from the positions in LDS in every pass: holding 16 doubles across the
+                // passes costs 32 registers, which the kernel does not have - the compiler then spills around this branch on
+                // the paths that never take it)
+                auto d2 = [&](int r) -> double {
                     const int j = FR(r) + 4 * lh;
                     const float2 pj = *reinterpret_cast<const float2 *>(pos + j * 2);
                     const double dx = (double)xa - (double)pj.x, dy = (double)ya - (double)pj.y;
-                    dq[r] = ((j >= s0) & (j < s0 + n)) ? dx * dx + dy * dy : (double)INFINITY;
-                }
+                    // spelled out (product rounded, then one fma): every pass must get the SAME bits for a candidate, or the
+                    // "greater than the previous key" test stops excluding it - left to the compiler, one inlined copy was
+                    // contracted differently from another
+                    return ((j >= s0) & (j < s0 + n)) ? __builtin_fma(dx, dx, __dmul_rn(dy, dy)) : (double)INFINITY;
+                };
                 const int kk = min(R.top_k, n);
                 double pd = -1.0;
                 int pj = -1;
                 for (int p = 0; p < R.top_k && p < 32; ++p) {
                     double cd = (double)INFINITY;
                     int cj = 64;
-    #pragma unroll
+    #pragma unroll 4
                     for (int r = 0; r < 16; ++r) {
                         const int j = FR(r) + 4 * lh;
-                        const bool gt = (dq[r] > pd) | ((dq[r] == pd) & (j > pj));
-                        const bool lt = (dq[r] < cd) | ((dq[r] == cd) & (j < cj));
-                        if (gt & lt) { cd = dq[r]; cj = j; }
+                        const double dr = d2(r);
+                        const bool gt = (dr > pd) | ((dr == pd) & (j > pj));
+                        const bool lt = (dr < cd) | ((dr == cd) & (j < cj));
+                        if (gt & lt) { cd = dr; cj = j; }
                     }
                     const double od = __shfl_xor(cd, 32);
                     const int oj = __shfl_xor(cj, 32);
                     if ((od < cd) | ((od == cd) & (oj < cj))) { cd = od; cj = oj; }
                     if (p < kk) { pd = cd; pj = cj; }       // a scene smaller than top_k has all its columns on after n passes
                 }
-    #pragma unroll
+    #pragma unroll 4
                 for (int r = 0; r < 16; ++r) {
                     const int j = FR(r) + 4 * lh;
-                    const bool on = (j >= s0) & (j < s0 + n) & ((dq[r] < pd) | ((dq[r] == pd) & (j <= pj)));
+                    const double dr = d2(r);
+                    const bool on = (j >= s0) & (j < s0 + n) & ((dr < pd) | ((dr == pd) & (j <= pj)));
                     mk |= on ? (1u << r) : 0u;
                 }
                 amask = mk;

@@ -13,7 +13,7 @@ import os
 import sys
 
 src, tag, workload = sys.argv[1], sys.argv[2], sys.argv[3]
-out = {"command": f"python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload {workload}; one rocprofv3 --pmc pass per counter group",
+out = {"command": f"python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-reference-loop --workload {workload}; one rocprofv3 --pmc pass per counter group",
        "units": "FETCH_SIZE / WRITE_SIZE in KiB per launch (mean over launches)", "kernels": {}}
 for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
     path = os.path.join(src, name, "c_counter_collection.csv")
@@ -21,9 +21,14 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq"):
         continue
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     seen = collections.defaultdict(set)
-    for r in csv.DictReader(open(path)):
+    rows = [r for r in csv.DictReader(open(path)) if "rollout" in r["Kernel_Name"] or "gemm" in r["Kernel_Name"]]
+    # only the full-size launches of a kernel (the bench also launches it on small batches: plan warm-up, forward_obs_ms)
+    big = collections.defaultdict(int)
+    for r in rows:
+        big[r["Kernel_Name"]] = max(big[r["Kernel_Name"]], int(r["Grid_Size"]))
+    for r in rows:
         k = r["Kernel_Name"]
-        if "rollout" not in k and "gemm" not in k:
+        if int(r["Grid_Size"]) != big[k]:
             continue
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
         seen[k].add(r["Dispatch_Id"])

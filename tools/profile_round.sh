@@ -7,7 +7,8 @@ WORKLOAD=${2:-dagnet_bsk_4096x20}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload $WORKLOAD"
+# the untimed legs (CPU baselines, the K x sample() reference loop) are skipped: they launch the same kernels at other sizes
+ARGS="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-reference-loop --workload $WORKLOAD"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 $ARGS > $OUT/trace.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o c -- python3 $ARGS > $OUT/pmc_fetch.log 2>&1
 timeout -s KILL 200 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o c -- python3 $ARGS > $OUT/pmc_write.log 2>&1

@@ -460,6 +460,141 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
     }
 }
 
+// All H heads of a scene in ONE single-wave workgroup (H > 1: the hidden and goal graphs' 4 x 8 heads).  The per-(scene, head)
+// kernels above are bound by the latency chain of a workgroup's life (scene_ptr -> block offset -> Wh, then eight short phases),
+// not by arithmetic: 4 x 8192 workgroups of a few hundred FMAs each ran 35 us forward / 69 us backward per call.  Here the
+// scene's [n][H F] slab of Wh is read once (whole rows, coalesced), every phase runs over (head, ...) jointly - the same
+// number of barriers for four heads as for one - and a quarter of the workgroups is dispatched.
+// dynamic LDS forward: wh [n][HF] | s1 [H][n] | s2 [H][n] | att [H][n][n]
+__device__ __forceinline__ void gat_logits_heads(int n, int H, int F, int64_t rld, const float *wh, const float *a, const float *ablk,
+                                                 float alpha, float *s1, float *s2, float *att, int tid) {
+    const int HF = H * F, nn = n * n;
+    for (int e = tid; e < H * 2 * n; e += GAT_T) {
+        const int hd = e / (2 * n), r = e - hd * 2 * n, i = r >> 1, w = r & 1;
+        const float *ah = a + (int64_t)hd * 2 * F + w * F;
+        float u = 0.f;
+        for (int f = 0; f < F; ++f) u += wh[i * HF + hd * F + f] * ah[f];
+        (w ? s2 : s1)[hd * n + i] = u;
+    }
+    __syncthreads();
+    for (int e = tid; e < H * nn; e += GAT_T) {
+        const int hd = e / nn, ij = e - hd * nn, i = ij / n, j = ij - i * n;
+        const float v = s1[hd * n + i] + s2[hd * n + j];
+        att[e] = ablk[i * rld + j] > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
+    }
+    __syncthreads();
+    for (int e = tid; e < H * n; e += GAT_T) {
+        float *row = att + (int64_t)e * n;          // e = hd * n + i
+        float mx = -INFINITY;
+        for (int j = 0; j < n; ++j) mx = fmaxf(mx, row[j]);
+        float sum = 0.f;
+        for (int j = 0; j < n; ++j) {
+            const float w = row[j] == -INFINITY ? 0.f : expf(row[j] - mx);
+            row[j] = w;
+            sum += w;
+        }
+        const float inv = 1.0f / sum;
+        for (int j = 0; j < n; ++j) row[j] *= inv;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(GAT_T) void gat_attn_fwd_heads_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
+                                                                int64_t ldw, const float *__restrict__ a, int H, int F, float alpha, int elu,
+                                                                float *__restrict__ Out, int64_t ldo) {
+    extern __shared__ float sm[];
+    const int s = blockIdx.x;
+    const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, HF = H * F, nn = n * n;
+    float *wh = sm, *s1 = wh + n * HF, *s2 = s1 + H * n, *att = s2 + H * n;
+    const float *ablk = adj + sc.off[s];
+    const int64_t rld = sc.ld ? sc.ld : n;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * HF; e += GAT_T) {
+        const int i = e / HF;
+        wh[e] = Wh[(int64_t)(b + i) * ldw + (e - i * HF)];
+    }
+    __syncthreads();
+    gat_logits_heads(n, H, F, rld, wh, a, ablk, alpha, s1, s2, att, tid);
+    for (int e = tid; e < n * HF; e += GAT_T) {
+        const int i = e / HF, c = e - i * HF, hd = c / F;
+        const float *arow = att + hd * nn + i * n;
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) acc += arow[j] * wh[j * HF + c];
+        if (elu) acc = acc > 0.f ? acc : expm1f(acc);
+        Out[(int64_t)(b + i) * ldo + c] = acc;
+    }
+}
+
+// dynamic LDS backward: wh [n][HF] | dO [n][HF] | s1 | s2 | ds1 | ds2 | dot [H][n] each | att [H][n][n] | dpre [H][n][n]
+__global__ __launch_bounds__(GAT_T) void gat_attn_bwd_heads_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
+                                                                int64_t ldw, const float *__restrict__ a, int H, int F, float alpha, int elu,
+                                                                const float *__restrict__ Out, int64_t ldo, const float *__restrict__ dOut,
+                                                                int64_t ldd, float *__restrict__ dWh, int64_t ldg,
+                                                                float *__restrict__ da_part) {
+    extern __shared__ float sm[];
+    const int s = blockIdx.x;
+    const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, HF = H * F, nn = n * n, Hn = H * n;
+    float *wh = sm, *dO = wh + n * HF, *s1 = dO + n * HF, *s2 = s1 + Hn, *ds1 = s2 + Hn, *ds2 = ds1 + Hn, *dot = ds2 + Hn;
+    float *att = dot + Hn, *dpre = att + H * nn;
+    const float *ablk = adj + sc.off[s];
+    const int64_t rld = sc.ld ? sc.ld : n;
+    const int tid = threadIdx.x;
+    for (int e = tid; e < n * HF; e += GAT_T) {
+        const int i = e / HF, c = e - i * HF;
+        const int64_t row = b + i;
+        wh[e] = Wh[row * ldw + c];
+        float g = dOut[row * ldd + c];
+        if (elu) { const float o = Out[row * ldo + c]; g *= o > 0.f ? 1.f : o + 1.f; }
+        dO[e] = g;
+    }
+    __syncthreads();
+    gat_logits_heads(n, H, F, rld, wh, a, ablk, alpha, s1, s2, att, tid);
+    // d att_ij = dO_i . Wh_j (per head)
+    for (int e = tid; e < H * nn; e += GAT_T) {
+        const int hd = e / nn, ij = e - hd * nn, i = ij / n, j = ij - i * n;
+        float d = 0.f;
+        for (int f = 0; f < F; ++f) d += dO[i * HF + hd * F + f] * wh[j * HF + hd * F + f];
+        dpre[e] = d;
+    }
+    __syncthreads();
+    for (int e = tid; e < Hn; e += GAT_T) {         // e = hd * n + i
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) acc += att[e * n + j] * dpre[e * n + j];
+        dot[e] = acc;
+    }
+    __syncthreads();
+    for (int e = tid; e < H * nn; e += GAT_T) {
+        const int hd = e / nn, ij = e - hd * nn, i = ij / n, j = ij - i * n;
+        const float v = s1[hd * n + i] + s2[hd * n + j];
+        dpre[e] = att[e] * (dpre[e] - dot[hd * n + i]) * (v > 0.f ? 1.f : alpha);
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * Hn; e += GAT_T) {
+        const int hi = e >> 1, hd = hi / n, i = hi - hd * n;
+        const float *dp = dpre + hd * nn;
+        float acc = 0.f;
+        if (e & 1) { for (int k = 0; k < n; ++k) acc += dp[k * n + i]; ds2[hi] = acc; }
+        else       { for (int k = 0; k < n; ++k) acc += dp[i * n + k]; ds1[hi] = acc; }
+    }
+    __syncthreads();
+    for (int e = tid; e < n * HF; e += GAT_T) {
+        const int j = e / HF, c = e - j * HF, hd = c / F, f = c - hd * F;
+        const float *ah = a + (int64_t)hd * 2 * F;
+        float acc = ds1[hd * n + j] * ah[f] + ds2[hd * n + j] * ah[F + f];
+        const float *ap = att + hd * nn;
+        for (int i = 0; i < n; ++i) acc += ap[i * n + j] * dO[i * HF + c];
+        dWh[(int64_t)(b + j) * ldg + c] = acc;
+    }
+    for (int e = tid; e < H * 2 * F; e += GAT_T) {
+        const int hd = e / (2 * F), f = e - hd * 2 * F;
+        const float *ds = (f < F ? ds1 : ds2) + hd * n;
+        const int ff = f < F ? f : f - F;
+        float acc = 0.f;
+        for (int i = 0; i < n; ++i) acc += ds[i] * wh[i * HF + hd * F + ff];
+        da_part[((int64_t)s * H + hd) * 2 * F + f] = acc;
+    }
+}
+
 // GCN aggregation (gcn_layers.py:20-26): Y_i = sum_j adj_ij X_j (+ bias);  transpose: Y_j = sum_i adj_ij X_i (backward)
 __global__ void adj_matmul_kernel(Scenes sc, const int32_t *__restrict__ row_scene, int64_t Nrows, int F, const float *__restrict__ adj,
                                   const float *__restrict__ X, int64_t ldx, const float *__restrict__ bias, int transpose,
@@ -712,6 +847,11 @@ extern "C" hipError_t dn_t_gat_attn_fwd(const int32_t *scene_ptr, const int64_t 
     const int64_t lds = dn_t_gat_lds_bytes(n_max, F, 0);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     tops::Scenes sc{scene_ptr, off_compact, S, adj_ld};
+    if (H > 1 && H * lds <= 40 * 1024) {        // all heads of a scene in one workgroup (at least 4 workgroups per CU)
+        hipLaunchKernelGGL(tops::gat_attn_fwd_heads_kernel, dim3(S), dim3(GAT_T), (size_t)(H * lds), st, sc, adj, Wh, ldw, a, H, F, alpha, elu,
+                           Out, ldo);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(tops::gat_attn_fwd_kernel, dim3(S, H), dim3(GAT_T), (size_t)lds, st, sc, adj, Wh, ldw, a, F, alpha, elu, Out, ldo);
     return hipGetLastError();
 }
@@ -722,6 +862,11 @@ extern "C" hipError_t dn_t_gat_attn_bwd(const int32_t *scene_ptr, const int64_t 
     const int64_t lds = dn_t_gat_lds_bytes(n_max, F, 1);
     if (lds > 64 * 1024) return hipErrorInvalidValue;
     tops::Scenes sc{scene_ptr, off_compact, S, adj_ld};
+    if (H > 1 && H * lds <= 40 * 1024) {
+        hipLaunchKernelGGL(tops::gat_attn_bwd_heads_kernel, dim3(S), dim3(GAT_T), (size_t)(H * lds), st, sc, adj, Wh, ldw, a, H, F, alpha, elu,
+                           Out, ldo, dOut, ldd, dWh, ldg, da_part);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(tops::gat_attn_bwd_kernel, dim3(S, H), dim3(GAT_T), (size_t)lds, st, sc, adj, Wh, ldw, a, F, alpha, elu, Out, ldo, dOut,
                        ldd, dWh, ldg, da_part);
     return hipGetLastError();

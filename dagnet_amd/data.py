@@ -7,8 +7,9 @@ stored back to back here (time-major ``[T, N_all, C]`` plus a CSR ``scene_ptr``)
 slice and a shuffled batch one ``index_select`` of rows - on the device, with no per-scene Python work
 (``SceneBatcher``).  The tuples handed to the models are the reference's, field by field.
 
-Reading the datasets' files (``trajectories.npy`` / ``goals.npy``, the SDD ``.npy`` windows) is plain numpy and not
-part of the hot path; ``BasketDataset`` accepts the arrays directly or the directory the reference reads them from.
+Reading the datasets' files (``trajectories.npy`` / ``goals.npy``, the SDD tracks) is plain numpy and not part of the hot
+path; ``BasketDataset`` accepts the arrays directly or the directory the reference reads them from, ``TrajectoryDataset``
+(loader_sdd.py:65-227, the SDD window extraction) the reference's ``.npy`` file or the list of tracks.
 """
 from __future__ import annotations
 
@@ -116,6 +117,130 @@ class BasketDataset(torch.utils.data.Dataset):
     def fields(self):
         """The six time-major tensors of the whole split, in the order of the collated tuple."""
         return [self.obs_traj, self.pred_traj, self.obs_traj_rel, self.pred_traj_rel, self.obs_goals, self.pred_goals]
+
+
+def poly_fit(traj, traj_len, threshold):
+    """loader_sdd.py:45-62: 1.0 when the residuals of a quadratic fit to the last ``traj_len`` steps of ``traj [2, T]``
+    reach ``threshold`` (non-linear trajectory), else 0.0.  Same numpy call as the reference: same bits."""
+    t = np.linspace(0, traj_len - 1, traj_len)
+    res_x = np.polyfit(t, traj[0, -traj_len:], 2, full=True)[1]
+    res_y = np.polyfit(t, traj[1, -traj_len:], 2, full=True)[1]
+    return 1.0 if res_x + res_y >= threshold else 0.0
+
+
+class TrajectoryDataset(torch.utils.data.Dataset):
+    """loader_sdd.py:65-227: sliding windows of ``obs_len + pred_len`` frames over the Stanford Drone Dataset tracks.
+
+    ``source``: the ``.npy`` file the reference reads (an object array of ``(scene_name, data [rows, 4])`` with rows
+    ``frame, pedestrian, x, y``; ``limits.json`` two directories above it), or a pair ``(files, scene_limits)`` with
+    ``files`` a list of such tuples and ``scene_limits`` the dictionary of that json.
+    Behaviour kept from the reference, quirks included: positions rounded to 4 decimals; a pedestrian counts only if it spans the
+    whole window; and because the reference tests ``num_peds_considered > min_ped`` INSIDE its pedestrian loop
+    (loader_sdd.py:166-172), a window with m accepted pedestrians contributes the sequences of its first
+    ``min_ped + 1, min_ped + 2, ..., m`` pedestrians - growing prefixes of one window - and ``non_linear_ped`` repeats
+    the flags of every prefix; its length therefore differs from the number of rows, as in the reference.
+    The per-window work is numpy on sorted frame / pedestrian indices (one lexsort per file) instead of a boolean scan of the
+    file per frame and per pedestrian."""
+
+    def __init__(self, source, obs_len, pred_len, set="train", skip=1, n_cells_x=16, n_cells_y=15, goals_window=4, disable=True,
+                 threshold=0.002, min_ped=1):
+        super().__init__()
+        import json
+        import math
+        import pathlib
+        self.obs_len, self.pred_len, self.skip = obs_len, pred_len, skip
+        self.seq_len = S = obs_len + pred_len
+        self.n_cells_x, self.n_cells_y, self.goals_window = n_cells_x, n_cells_y, goals_window
+        if isinstance(source, (str, os.PathLike)):
+            self.data_dir = source
+            root = pathlib.Path(source).parent.parent.absolute()
+            with open(os.path.join(root, "limits.json")) as fh:
+                scene_limits = json.load(fh)
+            all_files = np.load(source, allow_pickle=True)        # the reference's own container format (the caller's file)
+        else:
+            all_files, scene_limits = source
+        num_peds_in_seq, loss_masks, non_linear, seqs, seqs_rel, goals = [], [], [], [], [], []
+        for file in all_files:
+            scene_name, data = file[0], np.asarray(file[1], dtype=np.float64)
+            frames = np.unique(data[:, 0])
+            fidx = np.searchsorted(frames, data[:, 0])                  # frame number -> position in the frame list
+            # rows grouped by frame in their original order (the reference concatenates per-frame selections)
+            order = np.argsort(fidx, kind="stable")
+            data, fidx = data[order], fidx[order]
+            fstart = np.searchsorted(fidx, np.arange(len(frames) + 1))
+            in_file = []
+            num_sequences = int(math.ceil((len(frames) - S + 1) / skip))
+            for idx in range(0, num_sequences * skip + 1, skip):
+                lo, hi = fstart[min(idx, len(frames))], fstart[min(idx + S, len(frames))]
+                if hi <= lo:
+                    continue            # (the reference's np.concatenate of an empty list raises here; cannot happen for skip = 1)
+                w, wf = data[lo:hi], fidx[lo:hi]
+                # rows of the window grouped by pedestrian (ids ascending = np.unique's order), frames ascending inside
+                po = np.lexsort((np.arange(hi - lo), w[:, 1]))
+                w, wf = w[po], wf[po]
+                pstart = np.flatnonzero(np.r_[True, w[1:, 1] != w[:-1, 1], True])
+                m_all = len(pstart) - 1
+                curr_seq, curr_rel, curr_mask = np.zeros((m_all, 2, S)), np.zeros((m_all, 2, S)), np.zeros((m_all, S))
+                cnt, nl = 0, []
+                for a, b in zip(pstart[:-1], pstart[1:]):
+                    pad_front, pad_end = int(wf[a]) - idx, int(wf[b - 1]) - idx + 1
+                    if pad_end - pad_front != S:
+                        continue
+                    xy = np.transpose(np.around(w[a:b], decimals=4)[:, 2:])
+                    if xy.shape[1] != S:
+                        raise ValueError("could not broadcast input array: a track with missing frames spans the window "
+                                         "(the reference fails on this input too)")
+                    rel = np.zeros(xy.shape)
+                    rel[:, 1:] = xy[:, 1:] - xy[:, :-1]
+                    curr_seq[cnt, :, pad_front:pad_end] = xy
+                    curr_rel[cnt, :, pad_front:pad_end] = rel
+                    nl.append(poly_fit(xy, pred_len, threshold))
+                    curr_mask[cnt, pad_front:pad_end] = 1
+                    cnt += 1
+                    if cnt > min_ped:                       # inside the loop, as in the reference: one entry per prefix
+                        non_linear += nl
+                        num_peds_in_seq.append(cnt)
+                        loss_masks.append(curr_mask[:cnt])
+                        in_file.append(curr_seq[:cnt])
+                        seqs.append(curr_seq[:cnt])
+                        seqs_rel.append(curr_rel[:cnt])
+            if in_file:
+                all_traj = np.concatenate(in_file, axis=0)                                  # [rows, 2, S]
+                x_min, x_max, y_min, y_max = scene_limits[scene_name].values()
+                goals.append(compute_goals_fixed(all_traj.swapaxes(1, 2), x_min, x_max, y_min, y_max, n_cells_x, n_cells_y,
+                                                 window=goals_window))
+        if not seqs:
+            raise ValueError("need at least one array to concatenate")          # numpy's message in the reference
+        self.num_seq = len(seqs)
+        self.seq_list, self.seq_list_rel = np.concatenate(seqs, axis=0), np.concatenate(seqs_rel, axis=0)
+        goals = np.concatenate(goals, axis=0)
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).type(torch.float)     # noqa: E731
+        self.obs_traj, self.pred_traj = f(self.seq_list[:, :, :obs_len]), f(self.seq_list[:, :, obs_len:])
+        self.obs_traj_rel, self.pred_traj_rel = f(self.seq_list_rel[:, :, :obs_len]), f(self.seq_list_rel[:, :, obs_len:])
+        self.obs_goals, self.pred_goals = f(goals[:, :obs_len]), f(goals[:, obs_len:])
+        self.loss_mask = f(np.concatenate(loss_masks, axis=0))
+        self.non_linear_ped = f(np.asarray(non_linear))
+        cum = [0] + np.cumsum(num_peds_in_seq).tolist()
+        self.seq_start_end = list(zip(cum, cum[1:]))
+        self.scene_ptr = np.asarray(cum, dtype=np.int64)
+        self.max_agents = max(num_peds_in_seq)
+
+    def __len__(self):
+        return self.num_seq
+
+    def __max_agents__(self):
+        return self.max_agents
+
+    def __getitem__(self, index):
+        a, b = self.seq_start_end[index]
+        return [self.obs_traj[a:b, :], self.pred_traj[a:b, :], self.obs_traj_rel[a:b, :], self.pred_traj_rel[a:b, :],
+                self.obs_goals[a:b], self.pred_goals[a:b], self.non_linear_ped[a:b], self.loss_mask[a:b, :]]
+
+    def fields(self):
+        """Time-major tensors of the whole split for ``SceneBatcher``, in the order of the SDD tuple's first six fields plus the
+        loss mask: obs / pred ``[T, N, 2]``, their relative versions, goals ``[T, N]``, loss mask ``[T_all, N]``."""
+        tm = [t.permute(2, 0, 1).contiguous() for t in (self.obs_traj, self.pred_traj, self.obs_traj_rel, self.pred_traj_rel)]
+        return tm + [self.obs_goals.t().contiguous(), self.pred_goals.t().contiguous()]
 
 
 class SceneBatcher:

@@ -331,6 +331,60 @@ def data_case():
     print("data_utils.npz:", len(out), "arrays")
 
 
+def sdd_tracks(seed=91):
+    """Synthetic Stanford-Drone-style tracks for the window extraction: per scene rows (frame, pedestrian, x, y), frames 12
+    apart, pedestrians entering and leaving at different frames, positions a random walk with more than 4 decimals, rows of a
+    frame in shuffled pedestrian order.  -> (list of (scene_name, data), limits dictionary)"""
+    rng = np.random.default_rng(seed)
+    files, limits = [], {}
+    for name, n_frames, spans in (("alpha_0", 30, [(0, 30), (2, 17), (5, 30), (0, 9), (11, 24), (3, 29), (20, 30)]),
+                                  ("beta_1", 25, [(0, 25), (0, 14), (6, 25), (8, 19)])):
+        rows = []
+        for ped, (a, b) in enumerate(spans):
+            xy = np.cumsum(rng.normal(scale=0.7, size=(b - a, 2)), axis=0) + rng.uniform(10, 40, size=2)
+            for k in range(b - a):
+                rows.append([12.0 * (a + k), 100.0 + 3 * ped, xy[k, 0], xy[k, 1]])
+        rows = np.asarray(rows)
+        rows = rows[np.lexsort((rng.permutation(len(rows)), rows[:, 0]))]
+        files.append((name, rows))
+        limits[name] = {"x_min": float(rows[:, 2].min() - 1), "x_max": float(rows[:, 2].max() + 1),
+                        "y_min": float(rows[:, 3].min() - 1), "y_max": float(rows[:, 3].max() + 1)}
+    return files, limits
+
+
+def sdd_windows_case():
+    """8(f) rank 2, the SDD window extraction (models/dagnet/data/loader_sdd.py:65-227) on synthetic tracks written in the
+    reference's own file layout (<root>/sdd_npy/train.npy + <root>/limits.json); skip 1 and 3.  Inputs stored with the outputs."""
+    import json
+    import tempfile
+    from models.dagnet.data import loader_sdd as ref_sdd
+    files, limits = sdd_tracks()
+    out = {"n_files": np.asarray(len(files))}
+    for i, (name, rows) in enumerate(files):
+        out[f"file{i}_rows"] = rows
+        out[f"file{i}_limits"] = np.asarray(list(limits[name].values()))
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "sdd_npy"))
+        with open(os.path.join(d, "limits.json"), "w") as fh:
+            json.dump(limits, fh)
+        arr = np.empty(len(files), dtype=object)
+        for i, f in enumerate(files):
+            arr[i] = f
+        path = os.path.join(d, "sdd_npy", "train.npy")
+        np.save(path, arr, allow_pickle=True)
+        for skip in (1, 3):
+            ds = ref_sdd.TrajectoryDataset(path, obs_len=4, pred_len=6, set="train", skip=skip, n_cells_x=5, n_cells_y=4,
+                                           goals_window=3, disable=True)
+            for k in ("obs_traj", "pred_traj", "obs_traj_rel", "pred_traj_rel", "obs_goals", "pred_goals", "loss_mask", "non_linear_ped"):
+                out[f"skip{skip}_{k}"] = getattr(ds, k).numpy()
+            out[f"skip{skip}_seq_start_end"] = np.asarray(ds.seq_start_end)
+            out[f"skip{skip}_len"] = np.asarray([len(ds), ds.__max_agents__()])
+            for j, t in enumerate(ds[3]):
+                out[f"skip{skip}_item3_{j}"] = t.numpy()
+    np.savez_compressed(os.path.join(OUT, "sdd_windows.npz"), **out)
+    print("sdd_windows.npz:", len(out), "arrays;", int(out["skip1_len"][0]), "sequences at skip 1")
+
+
 def layer_case():
     """Rows D1 / D3 / E3: the reference's stand-alone layers (gat_layers.py:25-40 with concat True / False,
     gcn_layers.py:20-26) on block-diagonal adjacencies of types 1 and 2, outputs plus the gradients of sum(out * probe)
@@ -469,7 +523,10 @@ def main():
         return multistep_cases()
     if len(sys.argv) > 1 and sys.argv[1] == "data":
         return data_case()
+    if len(sys.argv) > 1 and sys.argv[1] == "sdd_windows":
+        return sdd_windows_case()
     data_case()
+    sdd_windows_case()
     state_dict_layouts()
     train_cases()
     layer_case()

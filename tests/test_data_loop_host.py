@@ -149,3 +149,60 @@ def test_checkpoint_dictionary_layout(tmp_path):
     got = loop.load_checkpoint(fn, model2, opt2, loop.PlateauScheduler(opt2))
     assert got["epoch"] == 7 and opt2.step_count == 3 and torch.equal(opt2.m[0], opt.m[0])
     assert torch.equal(model2.weight, w_saved)
+
+
+# ------------------------------------------------------------------------------------------------
+# SDD window extraction (models/dagnet/data/loader_sdd.py:65-227) against the reference's own output
+# ------------------------------------------------------------------------------------------------
+SDD_GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "sdd_windows.npz"))
+
+
+def _sdd_source():
+    files, limits = [], {}
+    for i in range(int(SDD_GOLD["n_files"])):
+        name = f"scene{i}"
+        files.append((name, SDD_GOLD[f"file{i}_rows"]))
+        limits[name] = dict(zip(("x_min", "x_max", "y_min", "y_max"), SDD_GOLD[f"file{i}_limits"].tolist()))
+    return files, limits
+
+
+@pytest.mark.parametrize("skip", [1, 3])
+def test_sdd_trajectory_dataset_matches_the_reference_bit_for_bit(skip):
+    """tests/golden/sdd_windows.npz = the reference's TrajectoryDataset on synthetic tracks (oracle/make_golden.py sdd_windows):
+    windows, relative coordinates, 4-decimal rounding, goal cells, loss mask, the non-linearity flags and the reference's
+    growing-prefix sequences (its `> min_ped` test sits inside the pedestrian loop) - all bit-exact."""
+    from dagnet_amd import data
+    ds = data.TrajectoryDataset(_sdd_source(), obs_len=4, pred_len=6, skip=skip, n_cells_x=5, n_cells_y=4, goals_window=3)
+    for k in ("obs_traj", "pred_traj", "obs_traj_rel", "pred_traj_rel", "obs_goals", "pred_goals", "loss_mask", "non_linear_ped"):
+        want = SDD_GOLD[f"skip{skip}_{k}"]
+        got = getattr(ds, k).numpy()
+        assert got.shape == want.shape, k
+        assert np.array_equal(got, want), k
+    assert np.array_equal(np.asarray(ds.seq_start_end), SDD_GOLD[f"skip{skip}_seq_start_end"])
+    assert [len(ds), ds.__max_agents__()] == SDD_GOLD[f"skip{skip}_len"].tolist()
+    for j, t in enumerate(ds[3]):
+        assert np.array_equal(t.numpy(), SDD_GOLD[f"skip{skip}_item3_{j}"])
+    # the collated tuple of a DataLoader over it is what the models take
+    batch = data.seq_collate_sdd([ds[i] for i in range(4)])
+    assert batch[0].shape[0] == 4 and batch[4].shape[0] == 4 and batch[-1].shape == (4, 2)
+    # and the time-major fields feed SceneBatcher
+    sb = data.SceneBatcher(ds.fields(), ds.scene_ptr, 5, shuffle=False, device="cpu")
+    first = next(iter(sb))
+    assert torch.equal(first[0], ds.obs_traj[:int(ds.scene_ptr[5])].permute(2, 0, 1))
+
+
+def test_sdd_trajectory_dataset_reads_the_reference_file_layout(tmp_path):
+    """<root>/sdd_npy/train.npy (object array of (scene, rows)) + <root>/limits.json, as loader_sdd.py:97-98,107 read them."""
+    import json
+    from dagnet_amd import data
+    files, limits = _sdd_source()
+    (tmp_path / "sdd_npy").mkdir()
+    (tmp_path / "limits.json").write_text(json.dumps(limits))
+    arr = np.empty(len(files), dtype=object)
+    for i, f in enumerate(files):
+        arr[i] = f
+    np.save(tmp_path / "sdd_npy" / "train.npy", arr, allow_pickle=True)
+    ds = data.TrajectoryDataset(str(tmp_path / "sdd_npy" / "train.npy"), obs_len=4, pred_len=6, skip=1, n_cells_x=5, n_cells_y=4,
+                                goals_window=3)
+    assert np.array_equal(ds.obs_traj.numpy(), SDD_GOLD["skip1_obs_traj"])
+    assert np.array_equal(ds.pred_goals.numpy(), SDD_GOLD["skip1_pred_goals"])

@@ -19,7 +19,7 @@ from ._capi import DagnetHipError, _check, _stream
 ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
 OP_EXPORTS = (
-    "dagnet_op_gemm", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
+    "dagnet_op_gemm", "dagnet_op_gemm_dact", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
     "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
@@ -36,6 +36,7 @@ def _lib():
     if not _bound:
         vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
         lib.dagnet_op_gemm.argtypes = [vp, i64, vp, i64, i32, vp, vp, i64, i32, i32, i32, i32, f32, i32, vp, vp, i64, i64, vp]
+        lib.dagnet_op_gemm_dact.argtypes = [vp, i64, vp, i64, vp, i64, i32, f32, vp, i64, i32, vp, i64, i32, i32, i32, i32, vp]
         lib.dagnet_op_gemm_tn_workspace.argtypes = [i32, i32, i32]
         lib.dagnet_op_gemm_tn_workspace.restype = i64
         lib.dagnet_op_gemm_tn.argtypes = [vp, i64, vp, i64, vp, i64, vp, i32, i32, i32, vp, i32, vp]
@@ -129,6 +130,15 @@ def gemm(A, B, C_out, *, transb=False, bias=None, act=ACT_NONE, slope=0.01, accu
     K = A.shape[1] if K is None else K
     _check(_lib().dagnet_op_gemm(a, lda, b, ldb, int(transb), _p(bias), c, ldc, M, N, K, act, slope, int(accumulate),
                                  gather, _p(gidx), gs_g, gs_n, _stream(A.device)))
+
+
+def gemm_dact(dY, Y, dP, act, slope, B, C_out, *, transb=True, accumulate=False):
+    """dP = dY * act'(Y);  C = [C +] dP op(B)  - the activation backward fused into the first input-gradient product."""
+    (g, ldg), (y, ldy), (p, ldp), (b, ldb), (c, ldc) = _m(dY, "dY"), _m(Y, "Y"), _m(dP, "dP"), _m(B, "B"), _m(C_out, "C")
+    M, N = C_out.shape
+    K = dY.shape[1]
+    _check(_lib().dagnet_op_gemm_dact(g, ldg, y, ldy, p, ldp, act, slope, b, ldb, int(transb), c, ldc, M, N, K, int(accumulate),
+                                      _stream(dY.device)))
 
 
 def gemm_tn(A, B, C_out, accumulate=False, dbias=None):
@@ -392,12 +402,26 @@ class LinearFn(torch.autograd.Function):
         N, Ktot = W.shape
         M = y.shape[0]
         dy = _rows(dy)
+        # the activation backward rides on the first input-gradient product (one pass over dy and y instead of two)
+        fuse_at = -1
         if act != ACT_NONE:
             dpre = POOL.at(ctx.slot, "dpre", (M, N), y)
-            (g, ldg), (yy, ldy), (dp, ldp) = _m(dy), _m(y), _m(dpre)
-            _check(_lib().dagnet_op_act_bwd(M, N, g, ldg, yy, ldy, dp, ldp, act, slope, _stream(y.device)))
+            fuse_at = next((i for i in range(len(xs)) if ctx.needs_input_grad[8 + i]), -1)
+            if fuse_at < 0:
+                (g, ldg), (yy, ldy), (dp, ldp) = _m(dy), _m(y), _m(dpre)
+                _check(_lib().dagnet_op_act_bwd(M, N, g, ldg, yy, ldy, dp, ldp, act, slope, _stream(y.device)))
         else:
             dpre = dy
+        dxs = [None] * len(xs)
+        if fuse_at >= 0:
+            x, c0 = xs[fuse_at], cols[fuse_at]
+            gacc = ctx.gaccs[fuse_at]
+            if gacc is not None:
+                gemm_dact(dy, y, dpre, act, slope, W[:, c0:c0 + x.shape[1]], gacc.buffer(x), accumulate=gacc.started)
+                gacc.started = True
+            else:
+                dxs[fuse_at] = POOL.at(ctx.slot, "dx%d" % fuse_at, (M, x.shape[1]), y)
+                gemm_dact(dy, y, dpre, act, slope, W[:, c0:c0 + x.shape[1]], dxs[fuse_at])
         dW = db = None
         if ctx.needs_input_grad[0]:
             sink = _sink(ctx.W_param)
@@ -433,20 +457,15 @@ class LinearFn(torch.autograd.Function):
             else:
                 db = torch.empty(N, dtype=torch.float32, device=y.device)
                 colsum(dpre, db)
-        dxs = []
         for i, (x, c0) in enumerate(zip(xs, cols)):
-            if ctx.needs_input_grad[8 + i]:
+            if ctx.needs_input_grad[8 + i] and i != fuse_at:
                 gacc = ctx.gaccs[i]
                 if gacc is not None:            # a fan-out input (FanoutFn): add into the shared gradient buffer of the tensor
                     gemm(dpre, W[:, c0:c0 + x.shape[1]], gacc.buffer(x), transb=True, K=N, accumulate=gacc.started)
                     gacc.started = True
-                    dxs.append(None)
                     continue
-                dx = POOL.at(ctx.slot, "dx%d" % i, (M, x.shape[1]), y)
-                gemm(dpre, W[:, c0:c0 + x.shape[1]], dx, transb=True, K=N)
-                dxs.append(dx)
-            else:
-                dxs.append(None)
+                dxs[i] = POOL.at(ctx.slot, "dx%d" % i, (M, x.shape[1]), y)
+                gemm(dpre, W[:, c0:c0 + x.shape[1]], dxs[i], transb=True, K=N)
         return (dW, db, None, None, None, None, None, None, *dxs)
 
 

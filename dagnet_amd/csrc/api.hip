@@ -1562,6 +1562,31 @@ extern "C" int dagnet_op_gemm(const float *A, int64_t lda, const float *B, int64
     HIP_TRY(dn_gemm(A, lda, B, ldb, transb, bias, C, ldc, M, N, K, act, slope, accumulate, gather, gidx, gs_g, gs_n, OP_ST));
     return DAGNET_OK;
 }
+extern "C" hipError_t dn_gemm_skinny_dact(const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *P, int64_t ldp, int dact,
+                                          float dslope, const float *B, int64_t ldb, int transb, float *C, int64_t ldc, int M, int N,
+                                          int K, int accumulate, hipStream_t st);
+extern "C" hipError_t dn_t_act_bwd(int64_t M, int N, const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp,
+                                   int act, float slope, hipStream_t st);
+// dP = dY * act'(Y) and C = [C +] dP op(B) in one pass where the shape allows (gemm_skinny.hip), else as the two steps
+extern "C" int dagnet_op_gemm_dact(const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp, int32_t act,
+                                   float slope, const float *B, int64_t ldb, int32_t transb, float *C, int64_t ldc, int32_t M, int32_t N,
+                                   int32_t K, int32_t accumulate, void *stream) {
+    OP_NEED(M >= 0 && N >= 0 && K >= 0, "negative dimension");
+    if (M == 0 || K == 0) return DAGNET_OK;
+    OP_NEED(dY && Y && dP && B && C, "null operand");
+    OP_NEED(ldd >= K && ldy >= K && ldp >= K && ldc >= N && ldb >= (transb ? N : K), "row stride smaller than the row");
+    OP_NEED(act >= 0 && act <= 3, "unknown activation");
+    static const bool off = getenv("DAGNET_NO_DACT") != nullptr;
+    const hipError_t e = off ? hipErrorNotSupported
+                             : dn_gemm_skinny_dact(dY, ldd, Y, ldy, dP, ldp, act, slope, B, ldb, transb, C, ldc, M, N, K, accumulate, OP_ST);
+    if (e == hipErrorNotSupported) {
+        HIP_TRY(dn_t_act_bwd(M, K, dY, ldd, Y, ldy, dP, ldp, act, slope, OP_ST));
+        if (N > 0) HIP_TRY(dn_gemm(dP, ldp, B, ldb, transb, nullptr, C, ldc, M, N, K, 0, 0.f, accumulate, nullptr, nullptr, 0, 0, OP_ST));
+        return DAGNET_OK;
+    }
+    HIP_TRY(e);
+    return DAGNET_OK;
+}
 extern "C" int64_t dagnet_op_gemm_tn_workspace(int32_t M, int32_t N, int32_t K) { return dn_gemm_tn_workspace(M, N, K); }
 extern "C" int dagnet_op_gemm_tn(const float *A, int64_t lda, const float *B, int64_t ldb, float *C, int64_t ldc, float *dbias, int32_t M,
                                  int32_t N, int32_t K, float *workspace, int32_t accumulate, void *stream) {

@@ -34,6 +34,12 @@ struct Args {
     float slope;
     const float *gather; const int32_t *gidx; int64_t gs_g, gs_n;      // C[m][n] += gather[gidx[m] * gs_g + n * gs_n]
     int act, accumulate, transb;
+    // DACT form (the input-gradient product of a layer with an activation): the first operand is dY * act'(Y), computed on
+    // load from the layer's saved output Y [M, K]; the product dP = dY * act'(Y) is also written out (the weight-gradient
+    // product reads it later).  dact = ACT_* of the layer.
+    const float *Y; int64_t ldy;
+    float *P; int64_t ldp;
+    int dact; float dslope;
 };
 
 __device__ __forceinline__ float act_apply(int act, float v, float slope) {
@@ -61,7 +67,7 @@ __device__ __forceinline__ i32x4 make_rsrc(const void *base, int64_t bytes) {
 // Rows of A and C are 16-byte aligned with padded strides (lda >= 4 ceil(K / 4), ldc >= 4 ceil(N / 4)): float4 accesses.
 // WPS: workgroups per CU the register budget is cut for (512 / WPS registers per lane).
 // GATHER: the one-hot table term is present (its loads need registers of their own: they are issued before the MFMAs).
-template <int NT, int KG, int WPS, bool GATHER>
+template <int NT, int KG, int WPS, bool GATHER, bool DACT = false>
 __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
     extern __shared__ float wimg[];          // [NT][KG][64 lanes][4] weights, then [NT*32] bias (zero padded)
     float *bimg = wimg + NT * KG * 256;
@@ -108,10 +114,36 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
     const int kq = p.K - 4 * lh;
     constexpr bool PF = KG <= 12;            // wider A tiles (K = 192: the GRU gates' input gradient) do not fit twice
     f32x4 cur[KG], nxt[PF ? KG : 1];
+    f32x4 ynx[DACT ? KG : 1];                // DACT: the saved outputs of the tile in flight (same lanes, same k as its dY)
+    const i32x4 ry = make_rsrc(DACT ? p.Y : p.A, (int64_t)p.M * (DACT ? p.ldy : p.lda) * 4);
+    const i32x4 rp = make_rsrc(DACT ? (const float *)p.P : p.A, (int64_t)p.M * (DACT ? p.ldp : p.lda) * 4);
+    const int ldy4 = (int)p.ldy * 4, ldp4 = (int)p.ldp * 4;
     auto load_rows = [&](f32x4 (&dst)[KG], int t) {
         const int voff = (t * 32 + lr) * lda4 + 16 * lh;
 #pragma unroll
         for (int g = 0; g < KG; ++g) dst[g] = sk_load4(ra, voff + g * 32, 0, 0);
+        if constexpr (DACT) {
+            const int yoff = (t * 32 + lr) * ldy4 + 16 * lh;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) ynx[g] = sk_load4(ry, yoff + g * 32, 0, 0);
+        }
+    };
+    // dY -> dY * act'(Y) in place, and out to P (whole quads: columns of a straddling quad past K land in the row's padding)
+    auto dact = [&](f32x4 (&dst)[KG], int t) {
+        if constexpr (DACT) {
+            const int poff = (t * 32 + lr) * ldp4 + 16 * lh;
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float y = ynx[g][i];
+                    const float d = p.dact == ACT_LRELU ? (y > 0.f ? 1.f : p.dslope) : p.dact == ACT_RELU ? (y > 0.f ? 1.f : 0.f)
+                                    : p.dact == ACT_TANH ? 1.f - y * y : 1.f;
+                    dst[g][i] *= d;
+                }
+                if (8 * g + 4 * lh < p.K) sk_store4(dst[g], rp, poff + g * 32, 0, 0);
+            }
+        }
     };
     auto mask = [&](f32x4 (&dst)[KG]) {
 #pragma unroll
@@ -123,6 +155,7 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
     while (true) {
         const int ntile = tile + stride;
         const bool more = ntile < n_tiles;
+        dact(cur, tile);                     // consumes ynx (the current tile's Y) before the next tile's loads overwrite it
         if constexpr (PF) {
             if (more) load_rows(nxt, ntile);
         }
@@ -197,7 +230,7 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
     }
 }
 
-template <int NT, int KG, int WPS, bool GATHER>
+template <int NT, int KG, int WPS, bool GATHER, bool DACT = false>
 static hipError_t launch(const Args &a, hipStream_t st) {
     const size_t lds = ((size_t)NT * KG * 256 + NT * 32) * sizeof(float);
     const int64_t tiles = ((int64_t)a.M + 31) / 32;
@@ -208,10 +241,10 @@ static hipError_t launch(const Args &a, hipStream_t st) {
     const int64_t blocks = std::min<int64_t>((tiles + 3) / 4, 256 * per_cu);
     hipError_t e = hipSuccess;
     if (lds > 64 * 1024)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_kernel<NT, KG, WPS, GATHER>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds);
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(skinny_kernel<NT, KG, WPS, GATHER, DACT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((skinny_kernel<NT, KG, WPS, GATHER>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((skinny_kernel<NT, KG, WPS, GATHER, DACT>), dim3((unsigned)blocks), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
@@ -230,7 +263,7 @@ extern "C" hipError_t dn_gemm_skinny(const float *A, int64_t lda, const float *B
     if ((lda & 3) || (ldc & 3) || lda < ((K + 3) & ~3) || ldc < ((N + 3) & ~3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
         (reinterpret_cast<uintptr_t>(C) & 15))
         return hipErrorNotSupported;
-    skinny::Args a{A, lda, B, ldb, bias, C, ldc, M, N, K, slope, gather, gidx, gs_g, gs_n, act, accumulate, transb};
+    skinny::Args a{A, lda, B, ldb, bias, C, ldc, M, N, K, slope, gather, gidx, gs_g, gs_n, act, accumulate, transb, nullptr, 0, nullptr, 0, 0, 0.f};
     const int nt = (N + 31) / 32, kg = (K + 7) / 8;
     if (gather && nt > 3) return hipErrorNotSupported;
 #define SK_CASE(NTV, KGV, WPS)                                                                       \
@@ -246,5 +279,33 @@ extern "C" hipError_t dn_gemm_skinny(const float *A, int64_t lda, const float *B
     SK_CASE(3, 4, 4) SK_CASE(3, 8, 3) SK_CASE(3, 12, 2)
     SK_CASE(6, 4, 3) SK_CASE(6, 8, 2) SK_CASE(6, 12, 2)
 #undef SK_CASE
+    return hipErrorNotSupported;
+}
+
+// C[M,N] = [C +] (dY * act'(Y)) op(B), and P = dY * act'(Y): the input-gradient product of a layer y = act(x W^T + b) taken
+// straight from the gradient of its OUTPUT (dY [M,K], Y [M,K] the saved output, K = the layer's width), which replaces a pass
+// of its own over dY and Y (train_ops.hip act_bwd_kernel) plus the re-read of its result.  Same shape rules as dn_gemm_skinny,
+// for all three matrices of the first operand; -> hipErrorNotSupported otherwise (the caller runs the two steps separately).
+extern "C" hipError_t dn_gemm_skinny_dact(const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *P, int64_t ldp, int dact,
+                                          float dslope, const float *B, int64_t ldb, int transb, float *C, int64_t ldc, int M, int N,
+                                          int K, int accumulate, hipStream_t st) {
+    if (M < 2048 || N > 96 || K > 96 || N < 1 || K < 1) return hipErrorNotSupported;
+    const int64_t lim = 0x7fffffffLL;
+    if ((int64_t)M * ldd * 4 >= lim || (int64_t)M * ldy * 4 >= lim || (int64_t)M * ldp * 4 >= lim || (int64_t)M * ldc * 4 >= lim)
+        return hipErrorNotSupported;
+    const int k4 = (K + 3) & ~3;
+    if ((ldd & 3) || (ldy & 3) || (ldp & 3) || (ldc & 3) || ldd < k4 || ldy < k4 || ldp < k4 || ldc < ((N + 3) & ~3)) return hipErrorNotSupported;
+    if ((reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(P) | reinterpret_cast<uintptr_t>(C)) & 15)
+        return hipErrorNotSupported;
+    skinny::Args a{dY, ldd, B, ldb, nullptr, C, ldc, M, N, K, 0.f, nullptr, nullptr, 0, 0, skinny::ACT_NONE, accumulate, transb,
+                   Y, ldy, P, ldp, dact, dslope};
+    const int nt = (N + 31) / 32, kg = (K + 7) / 8;
+#define SK_DCASE(NTV, KGV, WPS) \
+    if (nt <= NTV && kg <= KGV) return skinny::launch<NTV, KGV, WPS, false, true>(a, st);
+    // registers: accumulators + dY of two tiles + Y of one
+    SK_DCASE(1, 4, 4) SK_DCASE(1, 8, 4) SK_DCASE(1, 12, 3)
+    SK_DCASE(2, 4, 4) SK_DCASE(2, 8, 3) SK_DCASE(2, 12, 2)
+    SK_DCASE(3, 4, 4) SK_DCASE(3, 8, 3) SK_DCASE(3, 12, 2)
+#undef SK_DCASE
     return hipErrorNotSupported;
 }

@@ -215,6 +215,12 @@ int dagnet_op_gemm_tn_finish(const float *part, float *C, int64_t ldc, float *db
 /* dP = dY * act'(.) through the saved layer output Y (backward of LeakyReLU / ReLU / tanh). */
 int dagnet_op_act_bwd(int64_t M, int32_t N, const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp,
                       int32_t act, float slope, void *stream);
+/* Replaces: the autograd of `act(F.linear(x, W, b))` from the gradient of the layer's OUTPUT down to the gradient of its input
+ * (models/dagnet/model.py:60-116 under loss.backward(), train_bsk.py:288): dP[M,K] = dY * act'(Y) (Y = the saved output, K = the
+ * layer's width) and C[M,N] = [C +] dP op(B) in one pass over dY and Y; dP stays for the weight-gradient product. */
+int dagnet_op_gemm_dact(const float *dY, int64_t ldd, const float *Y, int64_t ldy, float *dP, int64_t ldp, int32_t act, float slope,
+                        const float *B, int64_t ldb, int32_t transb, float *C, int64_t ldc, int32_t M, int32_t N, int32_t K,
+                        int32_t accumulate, void *stream);
 /* dst (+)= src for an [M,N] block (concatenations and their backward). */
 int dagnet_op_copy2d(int64_t M, int32_t N, const float *src, int64_t lds, float *dst, int64_t ldd, int32_t accumulate,
                      void *stream);

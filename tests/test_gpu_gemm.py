@@ -72,3 +72,28 @@ def test_gemm_unpadded_rows_take_the_tiled_kernel():
     C2 = torch.empty((3000, 90), device=DEV)
     _ops.gemm(C, W, C2, transb=True)
     torch.testing.assert_close(C2.double(), C.double() @ W.double(), rtol=2e-5, atol=2e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 64, 64), (3000, 20, 90), (2500, 90, 64), (2049, 64, 32), (5000, 2, 64), (1000, 64, 64), (2200, 128, 64)])
+@pytest.mark.parametrize("act", [_ops.ACT_LRELU, _ops.ACT_RELU, _ops.ACT_TANH])
+def test_gemm_dact_matches_the_two_steps(M, N, K, act):
+    """dagnet_op_gemm_dact: dP = dY * act'(Y), C = [C +] dP W (W [K, N'] as the slice of an nn.Linear weight) - fused in the skinny
+    kernel for M >= 2048, N, K <= 96, the two separate kernels otherwise; against torch in fp64."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K + act)
+    dY, Y, dP = _padded(M, K, g), _padded(M, K, g), _padded(M, K, g)
+    if act == _ops.ACT_TANH:
+        Y.copy_(torch.tanh(Y))
+    Wfull = (torch.randn((K, N + 9), generator=g) / K ** 0.5).to(DEV)
+    W = Wfull[:, 4:4 + N]                                       # [K, N] slice with row stride N + 9
+    d = {_ops.ACT_LRELU: torch.where(Y > 0, 1.0, 0.01), _ops.ACT_RELU: (Y > 0).float(), _ops.ACT_TANH: 1 - Y * Y}[act].double()
+    want_p = dY.double() * d
+    want_c = want_p @ W.double()
+    C = _padded(M, N, g)
+    _ops.gemm_dact(dY, Y, dP, act, 0.01, W, C)
+    torch.testing.assert_close(dP.double(), want_p, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(C.double(), want_c, rtol=2e-5, atol=2e-5)
+    C0 = torch.randn((M, N), generator=g).to(DEV)
+    C = _padded(M, N, g)
+    C.copy_(C0)
+    _ops.gemm_dact(dY, Y, dP, act, 0.01, W, C, accumulate=True)
+    torch.testing.assert_close(C.double(), C0.double() + want_c, rtol=2e-5, atol=2e-5)

@@ -8,6 +8,8 @@ All matrices are 2-D fp32 with unit column stride; a row-strided view (a column 
 """
 from __future__ import annotations
 
+import contextlib
+import os
 import ctypes as C
 from typing import Dict, Optional, Sequence
 
@@ -75,20 +77,22 @@ def _lib():
 # ---------------------------------------------------------------------------------------------
 # plumbing
 # ---------------------------------------------------------------------------------------------
-_scratch: Dict[torch.device, torch.Tensor] = {}
+_scratch: Dict[tuple, torch.Tensor] = {}
 _scratch_retired = []        # outgrown buffers stay alive: a captured hipGraph may have their address baked into its nodes
 
 
 def _ws(device, nfloats: int) -> torch.Tensor:
-    """Per-device scratch (split-reduction partials).  Kernels of one stream run in order, so one buffer is enough.
+    """Scratch per device AND stream (split-reduction partials).  Kernels of one stream run in order, so one buffer per stream
+    is enough; the branches of a training step (Branches) run on streams of their own and must not share one.
     A buffer that is outgrown is retired, never freed (training.GraphedForwardBackward replays launches that hold its
     pointer; handing the memory back to the caching allocator would let a replay scribble over another tensor)."""
-    t = _scratch.get(device)
+    key = (torch.device(device), torch.cuda.current_stream(device).cuda_stream)
+    t = _scratch.get(key)
     if t is None or t.numel() < nfloats:
         if t is not None:
             _scratch_retired.append(t)
         t = torch.empty(max(int(nfloats), 1 << 20), dtype=torch.float32, device=device)
-        _scratch[device] = t
+        _scratch[key] = t
     return t
 
 
@@ -185,6 +189,7 @@ class StepPool:
     def begin(self, T, device):
         """Sites reserved before the first next_t() are per-step (one slot): stacked weights, loop invariants."""
         self.T, self.t, self.n_site, self.active, self.device = int(T), -1, 0, True, torch.device(device)
+        BR.keep.clear()
 
     def next_t(self, t):
         self.t, self.n_site = int(t), 0
@@ -227,6 +232,62 @@ class StepPool:
 POOL = StepPool()
 
 
+class Branches:
+    """Side streams for the independent branches of a training step (training.forward_train): the prior, the goal head and
+    the decoder / NLL of a time step do not feed the recurrence, so they run beside the encoder -> phi_z -> GRU -> graph
+    chain instead of in line with it.  Every kernel of the step moves ~40 MB in ~17 us and leaves the chip half idle at its
+    head and tail; two or three such chains side by side fill those gaps (tools/ubench/graph_branches.py: 3 chains of 12
+    GEMMs 598 -> 395 us, also as branches of a captured hipGraph).  The backward pass follows by itself: autograd runs a
+    node's backward on the stream of its forward and orders the streams along the edges it knows.  What it does NOT know are
+    this module's side channels - fan-out gradient buffers (_GradAcc: used only by consumers on the alias's own stream),
+    stacked-weight and deferred weight-gradient records (their collectors join every side stream first), per-stream scratch (_ws).
+    DAGNET_TRAIN_STREAMS=0 keeps everything on one stream."""
+
+    def __init__(self):
+        self.enabled = os.environ.get("DAGNET_TRAIN_STREAMS", "1") != "0"
+        self.side = {}
+        self.keep = []           # events of the step in flight: one that is destroyed while the hipGraph capture that recorded it is
+                                 # still open takes the runtime down at capture end, so they live until the next step begins
+
+    def order(self, waiter, producer):
+        """``waiter`` continues after what ``producer`` has been given so far (stream.wait_stream with an event that stays alive)."""
+        ev = torch.cuda.Event()
+        ev.record(producer)
+        waiter.wait_event(ev)
+        self.keep.append(ev)
+
+    def _stream(self, name, device):
+        key = (name, torch.device(device))
+        st = self.side.get(key)
+        if st is None:
+            st = self.side[key] = torch.cuda.Stream(device=device)
+        return st
+
+    @contextlib.contextmanager
+    def fork(self, name, device):
+        """Run the block on side stream ``name``, ordered after everything issued on the current stream so far."""
+        if not (self.enabled and POOL.active):
+            yield
+            return
+        st = self._stream(name, device)
+        self.order(st, torch.cuda.current_stream(device))
+        with torch.cuda.stream(st):
+            yield
+
+    def join(self, *names, device=None):
+        """The current stream waits for what the named side streams (default: all) have been given so far."""
+        if not self.enabled:
+            return
+        for (name, dev), st in self.side.items():
+            if (not names or name in names) and (device is None or dev == torch.device(device)):
+                cur = torch.cuda.current_stream(dev)
+                if cur != st:
+                    self.order(cur, st)
+
+
+BR = Branches()
+
+
 class DeferredGrads:
     """Weight / bias gradients of sink parameters (training.attach_grad_arena).  The backward pass only RECORDS the operand
     pairs (dY_t, X_t) of every layer; at the end of the pass (autograd engine callback) the records of a layer are grouped
@@ -260,6 +321,7 @@ class DeferredGrads:
         flush_products(rec["items"], rec["dst"], rec["bias"], True)
 
     def finish(self):
+        BR.join()                # the records' operands were written on the branches' streams
         for key in list(self.recs):
             self.flush(key)
         self.pending = False
@@ -379,7 +441,7 @@ class LinearFn(torch.autograd.Function):
         M = xs[0].shape[0]
         ctx.slot = POOL.site()
         y = POOL.at(ctx.slot, "y", (M, N), xs[0])
-        ctx.gaccs = [getattr(x, "_hip_gacc", None) for x in xs]
+        ctx.gaccs = [_gacc_of(x) for x in xs]
         last = len(xs) - 1
         for s, (x, c0) in enumerate(zip(xs, cols)):
             Ks = x.shape[1]
@@ -418,7 +480,7 @@ class LinearFn(torch.autograd.Function):
             gacc = ctx.gaccs[fuse_at]
             if gacc is not None:
                 gemm_dact(dy, y, dpre, act, slope, W[:, c0:c0 + x.shape[1]], gacc.buffer(x), accumulate=gacc.started)
-                gacc.started = True
+                gacc.done()
             else:
                 dxs[fuse_at] = POOL.at(ctx.slot, "dx%d" % fuse_at, (M, x.shape[1]), y)
                 gemm_dact(dy, y, dpre, act, slope, W[:, c0:c0 + x.shape[1]], dxs[fuse_at])
@@ -462,7 +524,7 @@ class LinearFn(torch.autograd.Function):
                 gacc = ctx.gaccs[i]
                 if gacc is not None:            # a fan-out input (FanoutFn): add into the shared gradient buffer of the tensor
                     gemm(dpre, W[:, c0:c0 + x.shape[1]], gacc.buffer(x), transb=True, K=N, accumulate=gacc.started)
-                    gacc.started = True
+                    gacc.done()
                     continue
                 dxs[i] = POOL.at(ctx.slot, "dx%d" % i, (M, x.shape[1]), y)
                 gemm(dpre, W[:, c0:c0 + x.shape[1]], dxs[i], transb=True, K=N)
@@ -485,7 +547,7 @@ class MatmulFn(torch.autograd.Function):
         gemm(x, W, y, transb=True)
         ctx.save_for_backward(x, W)
         ctx.W_param = W
-        ctx.gacc = getattr(x, "_hip_gacc", None)
+        ctx.gacc = _gacc_of(x)
         ctx.wacc = getattr(W, "_hip_wacc", None)
         return y
 
@@ -497,7 +559,7 @@ class MatmulFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ctx.gacc is not None:
                 gemm(dy, W, ctx.gacc.buffer(x), accumulate=ctx.gacc.started)
-                ctx.gacc.started = True
+                ctx.gacc.done()
             else:
                 dx = POOL.at(ctx.slot, "dx", tuple(x.shape), x)
                 gemm(dy, W, dx)                       # dy [M,N] . W[K,N]^T
@@ -546,6 +608,7 @@ class StackFn(torch.autograd.Function):
     def backward(ctx, dout):
         wacc = ctx.wacc
         if wacc.products or wacc.colsums:
+            BR.join()            # the consumers that recorded these operands ran on the branches' streams
             total = POOL.at(ctx.slot, "dstack", ctx.oshape, wacc.products[0][0] if wacc.products else wacc.colsums[0])
             if wacc.products:
                 flush_products(wacc.products, total, None, False)
@@ -743,13 +806,29 @@ class CeFn(torch.autograd.Function):
 class _GradAcc:
     """Shared gradient buffer of a tensor with several consumers (FanoutFn)."""
 
-    def __init__(self, slot):
+    def __init__(self, slot, device):
         self.slot, self.started, self.buf = slot, False, None
+        # The buffer is a side channel that autograd does not see, so only consumers on the stream of the alias itself may use
+        # it (kernels of one stream run in order); a consumer on another branch's stream (Branches) returns its input gradient
+        # the ordinary way and autograd orders and adds it.  (An event chain between the writers' streams was tried first:
+        # hipStreamEndCapture does not return on the resulting graph.)
+        self.stream = torch.cuda.current_stream(device).cuda_stream
 
     def buffer(self, like):
         if self.buf is None:
             self.buf = POOL.at(self.slot, "gacc", tuple(like.shape), like)
         return self.buf
+
+    def done(self):
+        self.started = True
+
+
+def _gacc_of(x):
+    """The shared gradient buffer of a fan-out alias, for a consumer that runs on the alias's own stream; else None."""
+    g = getattr(x, "_hip_gacc", None)
+    if g is not None and g.stream != torch.cuda.current_stream(x.device).cuda_stream:
+        return None
+    return g
 
 
 class FanoutFn(torch.autograd.Function):
@@ -761,7 +840,7 @@ class FanoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         out = x.view_as(x)
-        ctx.gacc = _GradAcc(POOL.site())
+        ctx.gacc = _GradAcc(POOL.site(), x.device)
         ctx.set_materialize_grads(False)
         return out
 
@@ -770,9 +849,10 @@ class FanoutFn(torch.autograd.Function):
         acc = ctx.gacc
         if not acc.started:
             return g
+        buf = acc.buf                    # its writers ran on this stream
         if g is not None:
-            copy2d(_rows(g), acc.buf, accumulate=True)
-        return acc.buf
+            copy2d(_rows(g), buf, accumulate=True)
+        return buf
 
 
 def fanout(x):

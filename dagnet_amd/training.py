@@ -112,40 +112,50 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
                 st_goal = _ops.gat_stacks(model.graph_goals)
         h = [torch.zeros((N, R), dtype=torch.float32, device=dev) for _ in range(L)]
         k_rows, n_rows, c_rows = [], [], []
+        br = _ops.BR
         for t in range(1, T):
             pool.next_t(t)
             x_t = traj_rel[t]
             hl = h[-1]
+            # Three branches of the step feed only losses or the latent draw, not the recurrence: they go to side streams
+            # (_ops.Branches) and run beside the phi_x -> encoder -> phi_z -> GRU -> graph chain.
             if kind == "dagnet":
                 d_t = _ops.disposition(plan, traj[t], D)
                 g_prev, g_t = goals[t - 1], goals[t]
-                hid = linear(model.dec_goal[0], [d_t, hl], [0, D], act=ACT_RELU, gidx=g_prev, gcol=D + R, gdim=G)
-                dec_g = fan(SoftmaxFn.apply(linear(model.dec_goal[2], [hid], [0])))
-                g_graph = _graph(model.graph_goals, dec_g, adj[t], plan, st_goal)
-                g_comb = SoftmaxFn.apply(linear(model.lg_goals[0], [dec_g, g_graph], [0, G]))
-                c_rows.append(CeFn.apply(g_comb, g_t))
-                phi_x = fan(_mlp2(model.phi_x, [x_t], [0]))
+                with br.fork("goal", dev):          # goal head: ends in the CE rows
+                    hid = linear(model.dec_goal[0], [d_t, hl], [0, D], act=ACT_RELU, gidx=g_prev, gcol=D + R, gdim=G)
+                    dec_g = fan(SoftmaxFn.apply(linear(model.dec_goal[2], [hid], [0])))
+                    g_graph = _graph(model.graph_goals, dec_g, adj[t], plan, st_goal)
+                    g_comb = SoftmaxFn.apply(linear(model.lg_goals[0], [dec_g, g_graph], [0, G]))
+                    c_rows.append(CeFn.apply(g_comb, g_t))
+            with br.fork("prior", dev):             # prior: joins at the latent draw
+                if kind == "dagnet":
+                    prior = fan(_mlp2(model.prior, [hl], [G], gidx=g_t, gcol=0, gdim=G))
+                else:
+                    prior = fan(_mlp2(model.prior, [hl], [0]))
+                mu_p, lv_p = linear(model.prior_mean, [prior], [0]), linear(model.prior_logvar, [prior], [0])
+            phi_x = fan(_mlp2(model.phi_x, [x_t], [0]))
+            if kind == "dagnet":
                 enc = fan(_mlp2(model.enc, [phi_x, hl], [0, H + G], gidx=g_t, gcol=H, gdim=G))
-                prior = fan(_mlp2(model.prior, [hl], [G], gidx=g_t, gcol=0, gdim=G))
             else:
-                phi_x = fan(_mlp2(model.phi_x, [x_t], [0]))
                 enc = fan(_mlp2(model.enc, [phi_x, hl], [0, H]))
-                prior = fan(_mlp2(model.prior, [hl], [0]))
             mu_e, lv_e = linear(model.enc_mean, [enc], [0]), linear(model.enc_logvar, [enc], [0])
-            mu_p, lv_p = linear(model.prior_mean, [prior], [0]), linear(model.prior_logvar, [prior], [0])
+            br.join("prior", device=dev)
             z, k = VaeFn.apply(mu_e, lv_e, mu_p, lv_p, _eps(eps, t, N, Z, dev))
             k_rows.append(k)
             phi_z = fan(_mlp2(model.phi_z, [z], [0]))
-            if kind == "dagnet":
-                dec = fan(_mlp2(model.dec, [d_t, phi_z, hl], [0, D + G, D + G + H], gidx=g_t, gcol=D, gdim=G))
-            else:
-                dec = fan(_mlp2(model.dec, [phi_z, hl], [0, H]))
-            mu_d, lv_d = linear(model.dec_mean, [dec], [0]), linear(model.dec_logvar, [dec], [0])
+            with br.fork("dec", dev):               # decoder: ends in the NLL rows
+                if kind == "dagnet":
+                    dec = fan(_mlp2(model.dec, [d_t, phi_z, hl], [0, D + G, D + G + H], gidx=g_t, gcol=D, gdim=G))
+                else:
+                    dec = fan(_mlp2(model.dec, [phi_z, hl], [0, H]))
+                mu_d, lv_d = linear(model.dec_mean, [dec], [0]), linear(model.dec_logvar, [dec], [0])
+                n_rows.append(NllFn.apply(mu_d, lv_d, x_t))
             h = gru_step(model.rnn, [phi_x, phi_z], [0, H], h)
-            n_rows.append(NllFn.apply(mu_d, lv_d, x_t))
             if kind != "vrnn":
                 h_g = _graph(graph, h[-1], adj[t], plan, st_hid)
                 h[-1] = fan(linear(blend, [h_g, h[-1]], [0, R]))
+        br.join(device=dev)
         zero = torch.zeros(1, dtype=torch.float32, device=dev)
         kld = LossSumFn.apply(1.0 / N, *k_rows) if k_rows else zero
         nll = LossSumFn.apply(1.0 / N, *n_rows) if n_rows else zero
@@ -179,6 +189,7 @@ def train_step(model, optimizer: "_ops.ClipAdam", batch, kld_weight=1.0, ce_weig
         kld, nll, ce, _ = model(*batch, eps=eps)
         loss = row_fraction * (kld_weight * kld + nll) + ce_weight * ce
     loss.backward()
+    _ops.BR.join()                   # the branches' streams (forward_train) rejoin before the gradients are read
     allreduce_gradients(optimizer if getattr(optimizer, "arena", None) is not None else optimizer.params)
     optimizer.step()
     return dict(loss=loss.detach(), kld=kld.detach(), nll=nll.detach(), ce=ce.detach())
@@ -225,6 +236,7 @@ class GraphedForwardBackward:
                 zero()
                 loss, _ = loss_fn(model, *self.static)
                 loss.backward()
+                _ops.BR.join()
         torch.cuda.current_stream().wait_stream(side)
         if arena is None:
             zero()
@@ -234,6 +246,7 @@ class GraphedForwardBackward:
                 zero()
             self.loss, self.aux = loss_fn(model, *self.static)
             self.loss.backward()
+            _ops.BR.join()                       # every side stream of the step rejoins the capturing stream
 
     def __call__(self, *inputs):
         for dst, src in zip(self.static, inputs):

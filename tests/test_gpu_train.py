@@ -170,3 +170,63 @@ def test_checkpoint_resume_reproduces_the_third_step(name, tmp_path):
     ref_opt.load_state_dict(ck["optimizer_state_dict"])
     steps.append(_run_step(meta, fresh, opt2, 2))
     check_multistep(steps, _final(fresh, opt2), gold, meta)
+
+
+@pytest.mark.parametrize("kind,kw", [("dagnet", dict(n_layers=2)), ("avrnn", dict(n_layers=1)), ("vrnn", dict(n_layers=2))])
+def test_side_streams_do_not_change_the_step(kind, kw):
+    """training.forward_train forks the prior, the goal head and the decoder of every time step onto side streams
+    (_ops.Branches).  On 512 scenes x 10 agents x 12 steps - kernels long enough to overlap - the losses and every gradient
+    must equal the single-stream step (same weights, same noise) up to summation order, eagerly and as a replayed hipGraph."""
+    import dagnet_amd
+    from dagnet_amd import _ops, training, synthetic as syn
+    from dagnet_amd.adjacency_matrix import compute_adjs_distsim
+    a = syn.make_args(obs_len=4, pred_len=8, **kw)
+    sizes = [10] * 512
+    obs, gt, obs_rel, gt_rel, og, pg, sse = [t.to(DEV) for t in syn.make_batch(sizes, 4, 8, 17)]
+    traj, rel = torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0)
+    goals = torch.cat((og, pg), 0).to(torch.int32)
+    N = rel.shape[1]
+    eps = syn.uniform_noise(17, "eps", (rel.shape[0] - 1, N, a.z_dim)).to(DEV)
+
+    def run(streams, graphed):
+        m = {"vrnn": lambda: dagnet_amd.VRNN(a), "avrnn": lambda: dagnet_amd.AVRNN(a), "dagnet": lambda: dagnet_amd.DAGNet(a, 10)}[kind]()
+        m.load_state_dict(syn.random_state_dict(m, 23))
+        m = m.to(DEV).train()
+        adj = compute_adjs_distsim(a, sse, obs, gt, compact=True) if kind != "vrnn" else None
+        opt = _ops.ClipAdam(list(m.parameters()), lr=1e-3, clip=10.0)
+        training.attach_grad_arena(m, opt)
+
+        def loss_fn(mm, e):
+            if kind == "vrnn":
+                k, n, _ = mm(rel, eps=e)
+                c = torch.zeros_like(k)
+            elif kind == "avrnn":
+                k, n, _ = mm(rel, adj, seq_start_end=sse, eps=e)
+                c = torch.zeros_like(k)
+            else:
+                k, n, c, _ = mm(traj, rel, goals, sse, adj, eps=e)
+            return k + n + 1e-2 * c, (k, n, c)
+        was = _ops.BR.enabled
+        _ops.BR.enabled = streams
+        try:
+            if graphed:
+                gfb = training.GraphedForwardBackward(m, loss_fn, [eps])
+                loss, aux = gfb(eps)
+            else:
+                opt.zero_grad()
+                loss, aux = loss_fn(m, eps)
+                loss.backward()
+                _ops.BR.join()
+            torch.cuda.synchronize()
+        finally:
+            _ops.BR.enabled = was
+        return [float(v.detach()) for v in aux], {k_: p.grad.detach().clone() for k_, p in m.named_parameters()}
+    base_l, base_g = run(False, False)
+    for streams, graphed in ((True, False), (True, True)):
+        l, g = run(streams, graphed)
+        for x, y in zip(l, base_l):
+            assert abs(x - y) <= 1e-5 * max(1.0, abs(y)), (streams, graphed, l, base_l)
+        for k_ in base_g:
+            ref = base_g[k_]
+            tol = 1e-4 * float(ref.abs().max()) + 1e-6
+            assert float((g[k_] - ref).abs().max()) <= tol, (streams, graphed, k_)

@@ -71,6 +71,59 @@ __global__ void softmax_fwd_kernel(int64_t M, int N, const float *__restrict__ X
     for (int c = lane; c < N; c += 64) Y[r * ldy + c] = expf(x[c] - mx) * inv;
 }
 
+// Rows of at most 128 columns with 16-byte aligned rows (g_dim = 90 padded to a stride of 92): HALF a wave per row, one float4
+// per lane, the row held in registers between the passes (the kernels above spend a whole wave and three passes on 90 numbers).
+__device__ __forceinline__ float half_max(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__global__ void softmax_fwd4_kernel(int64_t M, int N, const float *__restrict__ X, int64_t ldx, float *__restrict__ Y, int64_t ldy) {
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int c = (threadIdx.x & 31) * 4;
+    const bool on = r < M && c < N;
+    float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    if (on) v = *reinterpret_cast<const float4 *>(X + r * ldx + c);
+    float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (c + i >= N) e[i] = -INFINITY;
+    const float mx = half_max(fmaxf(fmaxf(e[0], e[1]), fmaxf(e[2], e[3])));
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        e[i] = expf(e[i] - mx);
+        s += e[i];
+    }
+    const float inv = 1.0f / half_sum(s);
+    if (on) *reinterpret_cast<float4 *>(Y + r * ldy + c) = make_float4(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv);
+}
+__global__ void softmax_bwd4_kernel(int64_t M, int N, const float *__restrict__ Y, int64_t ldy, const float *__restrict__ dY, int64_t ldd,
+                                    float *__restrict__ dX, int64_t ldx) {
+    const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    const int c = (threadIdx.x & 31) * 4;
+    const bool on = r < M && c < N;
+    float4 y = make_float4(0.f, 0.f, 0.f, 0.f), g = y;
+    if (on) {
+        y = *reinterpret_cast<const float4 *>(Y + r * ldy + c);
+        g = *reinterpret_cast<const float4 *>(dY + r * ldd + c);
+    }
+    float ye[4] = {y.x, y.y, y.z, y.w}, ge[4] = {g.x, g.y, g.z, g.w};
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (c + i >= N) ye[i] = 0.f, ge[i] = 0.f;        // the row's padding is uninitialised
+        s += ge[i] * ye[i];
+    }
+    s = half_sum(s);
+    if (on) *reinterpret_cast<float4 *>(dX + r * ldx + c) = make_float4(ye[0] * (ge[0] - s), ye[1] * (ge[1] - s), ye[2] * (ge[2] - s), ye[3] * (ge[3] - s));
+}
+
 // dX = Y * (dY - sum(dY * Y))
 __global__ void softmax_bwd_kernel(int64_t M, int N, const float *__restrict__ Y, int64_t ldy, const float *__restrict__ dY, int64_t ldd,
                                    float *__restrict__ dX, int64_t ldx) {
@@ -236,6 +289,8 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(int64_t M, int N, int r
     float q0 = 0.f, q1 = 0.f;
     if (c < N) {
         const float mu = MODE >= 1 ? stat[c] : 0.f, is = MODE == 2 ? stat[N + c] : 0.f;
+        // four rows in flight per thread: the loop is a chain of dependent adds fed by loads the compiler will not batch by itself
+#pragma unroll 4
         for (int64_t m = m0 + rl; m < m1; m += 4) {
             if (MODE == 0) q0 += X[m * ldx + c];
             else if (MODE == 1) { const float d = X[m * ldx + c] - mu; q0 += d * d; }
@@ -679,13 +734,22 @@ extern "C" hipError_t dn_t_copy2d(int64_t M, int N, const float *src, int64_t ld
 }
 extern "C" hipError_t dn_t_softmax_fwd(int64_t M, int N, const float *X, int64_t ldx, float *Y, int64_t ldy, hipStream_t st) {
     if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(tops::softmax_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, N, X, ldx, Y, ldy);
+    const int n4 = (N + 3) & ~3;
+    if (N <= 128 && !(ldx & 3) && !(ldy & 3) && ldx >= n4 && ldy >= n4 && !((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(Y)) & 15))
+        hipLaunchKernelGGL(tops::softmax_fwd4_kernel, dim3((unsigned)((M + 7) / 8)), dim3(256), 0, st, M, N, X, ldx, Y, ldy);
+    else
+        hipLaunchKernelGGL(tops::softmax_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, N, X, ldx, Y, ldy);
     return hipGetLastError();
 }
 extern "C" hipError_t dn_t_softmax_bwd(int64_t M, int N, const float *Y, int64_t ldy, const float *dY, int64_t ldd, float *dX, int64_t ldx,
                                        hipStream_t st) {
     if (M == 0) return hipSuccess;
-    hipLaunchKernelGGL(tops::softmax_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, N, Y, ldy, dY, ldd, dX, ldx);
+    const int n4 = (N + 3) & ~3;
+    if (N <= 128 && !(ldy & 3) && !(ldd & 3) && !(ldx & 3) && ldy >= n4 && ldd >= n4 && ldx >= n4 &&
+        !((reinterpret_cast<uintptr_t>(Y) | reinterpret_cast<uintptr_t>(dY) | reinterpret_cast<uintptr_t>(dX)) & 15))
+        hipLaunchKernelGGL(tops::softmax_bwd4_kernel, dim3((unsigned)((M + 7) / 8)), dim3(256), 0, st, M, N, Y, ldy, dY, ldd, dX, ldx);
+    else
+        hipLaunchKernelGGL(tops::softmax_bwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, M, N, Y, ldy, dY, ldd, dX, ldx);
     return hipGetLastError();
 }
 extern "C" hipError_t dn_t_gru_fwd(int64_t M, int R, const float *gi, const float *gh, const float *h, float *hn, float *gates,

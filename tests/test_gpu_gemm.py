@@ -97,3 +97,25 @@ def test_gemm_dact_matches_the_two_steps(M, N, K, act):
     C.copy_(C0)
     _ops.gemm_dact(dY, Y, dP, act, 0.01, W, C, accumulate=True)
     torch.testing.assert_close(C.double(), C0.double() + want_c, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,N", [(5000, 90), (3001, 12), (4096, 128), (700, 200), (2048, 64)])
+@pytest.mark.parametrize("padded", [True, False])
+def test_softmax_op_matches_torch(M, N, padded):
+    """dagnet_op_softmax_fwd / _bwd (the goal distributions of the training step): half a wave per row for N <= 128 with
+    16-byte rows, a wave per row otherwise; NaN in the rows' padding must not leak."""
+    g = torch.Generator().manual_seed(M + N)
+    mk = (lambda: _padded(M, N, g)) if padded else (lambda: torch.randn((M, N), generator=g).to(DEV))
+    x = mk()
+    x.mul_(3.0)
+    y = mk()
+    lib = _ops._lib()
+    (xp, ldx), (yp, ldy) = _ops._m(x), _ops._m(y)
+    _ops._check(lib.dagnet_op_softmax_fwd(M, N, xp, ldx, yp, ldy, _ops._stream(x.device)))
+    want = torch.softmax(x.double(), dim=1)
+    torch.testing.assert_close(y.double(), want, rtol=1e-5, atol=1e-7)
+    dy, dx = mk(), mk()
+    (gp, ldg), (dp, ldd) = _ops._m(dy), _ops._m(dx)
+    _ops._check(lib.dagnet_op_softmax_bwd(M, N, yp, ldy, gp, ldg, dp, ldd, _ops._stream(x.device)))
+    yd, gd = y.double(), dy.double()
+    torch.testing.assert_close(dx.double(), yd * (gd - (gd * yd).sum(1, keepdim=True)), rtol=1e-5, atol=1e-6)

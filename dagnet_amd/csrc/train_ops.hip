@@ -389,6 +389,14 @@ struct Scenes {
 };
 
 #define GAT_T 64
+// e / d for 0 <= e < 2^16 with a divisor that is only known at run time (agents of the scene, head width): one v_mul_hi instead of
+// the ~35-instruction unsigned division - these kernels index everything by (row, feature) or (row, row) pairs of a flat e
+struct FastDiv {
+    uint32_t m;
+    int d;
+    __device__ explicit FastDiv(int d_) : m(d_ > 1 ? 0xffffffffu / (uint32_t)d_ + 1u : 0u), d(d_) {}
+    __device__ __forceinline__ int operator()(int e) const { return d > 1 ? (int)__umulhi((uint32_t)e, m) : e; }
+};
 // GAT attention of one layer (gat_layers.py:25-40) for H heads of width F stacked along the columns of Wh:
 //   s1_i = Wh_i . a[:F], s2_j = Wh_j . a[F:], e_ij = leakyrelu(s1_i + s2_j) where adj_ij > 0, att = softmax_j, out = att Wh (elu)
 // grid (S, H); dynamic LDS: Wh [n][F] | s1 [n] | s2 [n] | att [n][n].  Pair (i,j) and (row, feature) loops are spread over
@@ -402,8 +410,9 @@ __device__ __forceinline__ void gat_logits(int n, int F, int64_t rld, const floa
         (w ? s2 : s1)[i] = u;
     }
     __syncthreads();
+    const FastDiv dn(n);
     for (int e = tid; e < n * n; e += GAT_T) {
-        const int i = e / n, j = e - i * n;
+        const int i = dn(e), j = e - i * n;
         const float v = s1[i] + s2[j];
         att[e] = ablk[i * rld + j] > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
     }
@@ -434,11 +443,15 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_fwd_kernel(Scenes sc, const fl
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
-    for (int e = tid; e < n * F; e += GAT_T) wh[e] = Wh[(int64_t)(b + e / F) * ldw + hd * F + e % F];
+    const FastDiv dF(F);
+    for (int e = tid; e < n * F; e += GAT_T) {
+        const int i = dF(e);
+        wh[e] = Wh[(int64_t)(b + i) * ldw + hd * F + (e - i * F)];
+    }
     __syncthreads();
     gat_logits(n, F, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
     for (int e = tid; e < n * F; e += GAT_T) {
-        const int i = e / F, f = e % F;
+        const int i = dF(e), f = e - i * F;
         float acc = 0.f;
         for (int j = 0; j < n; ++j) acc += att[i * n + j] * wh[j * F + f];
         if (elu) acc = acc > 0.f ? acc : expm1f(acc);
@@ -462,9 +475,11 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
+    const FastDiv dF(F), dn(n);
     for (int e = tid; e < n * F; e += GAT_T) {
-        const int64_t row = b + e / F;
-        const int col = hd * F + e % F;
+        const int ii = dF(e);
+        const int64_t row = b + ii;
+        const int col = hd * F + (e - ii * F);
         wh[e] = Wh[row * ldw + col];
         float g = dOut[row * ldd + col];
         if (elu) { const float o = Out[row * ldo + col]; g *= o > 0.f ? 1.f : o + 1.f; }
@@ -474,7 +489,7 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
     gat_logits(n, F, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
     // d att_ij = dO_i . Wh_j
     for (int e = tid; e < n * n; e += GAT_T) {
-        const int i = e / n, j = e - i * n;
+        const int i = dn(e), j = e - i * n;
         float d = 0.f;
         for (int f = 0; f < F; ++f) d += dO[i * F + f] * wh[j * F + f];
         dpre[e] = d;
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
     __syncthreads();
     // d e_ij = att_ij (d att_ij - sum_k att_ik d att_ik), through the leaky relu
     for (int e = tid; e < n * n; e += GAT_T) {
-        const int i = e / n, j = e - i * n;
+        const int i = dn(e), j = e - i * n;
         const float v = s1[i] + s2[j];
         dpre[e] = att[e] * (dpre[e] - dot[i]) * (v > 0.f ? 1.f : alpha);
     }
@@ -501,7 +516,7 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
     }
     __syncthreads();
     for (int e = tid; e < n * F; e += GAT_T) {
-        const int j = e / F, f = e % F;
+        const int j = dF(e), f = e - j * F;
         float acc = ds1[j] * ah[f] + ds2[j] * ah[F + f];
         for (int i = 0; i < n; ++i) acc += att[i * n + j] * dO[i * F + f];
         dWh[(int64_t)(b + j) * ldg + hd * F + f] = acc;
@@ -524,8 +539,9 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
 __device__ __forceinline__ void gat_logits_heads(int n, int H, int F, int64_t rld, const float *wh, const float *a, const float *ablk,
                                                  float alpha, float *s1, float *s2, float *att, int tid) {
     const int HF = H * F, nn = n * n;
+    const FastDiv d2n(2 * n), dnn(nn), dn(n);
     for (int e = tid; e < H * 2 * n; e += GAT_T) {
-        const int hd = e / (2 * n), r = e - hd * 2 * n, i = r >> 1, w = r & 1;
+        const int hd = d2n(e), r = e - hd * 2 * n, i = r >> 1, w = r & 1;
         const float *ah = a + (int64_t)hd * 2 * F + w * F;
         float u = 0.f;
         for (int f = 0; f < F; ++f) u += wh[i * HF + hd * F + f] * ah[f];
@@ -533,7 +549,7 @@ __device__ __forceinline__ void gat_logits_heads(int n, int H, int F, int64_t rl
     }
     __syncthreads();
     for (int e = tid; e < H * nn; e += GAT_T) {
-        const int hd = e / nn, ij = e - hd * nn, i = ij / n, j = ij - i * n;
+        const int hd = dnn(e), ij = e - hd * nn, i = dn(ij), j = ij - i * n;
         const float v = s1[hd * n + i] + s2[hd * n + j];
         att[e] = ablk[i * rld + j] > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
     }
@@ -564,14 +580,15 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_fwd_heads_kernel(Scenes sc, co
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
+    const FastDiv dHF(HF), dF(F);
     for (int e = tid; e < n * HF; e += GAT_T) {
-        const int i = e / HF;
+        const int i = dHF(e);
         wh[e] = Wh[(int64_t)(b + i) * ldw + (e - i * HF)];
     }
     __syncthreads();
     gat_logits_heads(n, H, F, rld, wh, a, ablk, alpha, s1, s2, att, tid);
     for (int e = tid; e < n * HF; e += GAT_T) {
-        const int i = e / HF, c = e - i * HF, hd = c / F;
+        const int i = dHF(e), c = e - i * HF, hd = dF(c);
         const float *arow = att + hd * nn + i * n;
         float acc = 0.f;
         for (int j = 0; j < n; ++j) acc += arow[j] * wh[j * HF + c];
@@ -594,8 +611,9 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_heads_kernel(Scenes sc, co
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
+    const FastDiv dHF(HF), dF(F), dnn(nn), dn(n), d2F(2 * F);
     for (int e = tid; e < n * HF; e += GAT_T) {
-        const int i = e / HF, c = e - i * HF;
+        const int i = dHF(e), c = e - i * HF;
         const int64_t row = b + i;
         wh[e] = Wh[row * ldw + c];
         float g = dOut[row * ldd + c];
@@ -606,7 +624,7 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_heads_kernel(Scenes sc, co
     gat_logits_heads(n, H, F, rld, wh, a, ablk, alpha, s1, s2, att, tid);
     // d att_ij = dO_i . Wh_j (per head)
     for (int e = tid; e < H * nn; e += GAT_T) {
-        const int hd = e / nn, ij = e - hd * nn, i = ij / n, j = ij - i * n;
+        const int hd = dnn(e), ij = e - hd * nn, i = dn(ij), j = ij - i * n;
         float d = 0.f;
         for (int f = 0; f < F; ++f) d += dO[i * HF + hd * F + f] * wh[j * HF + hd * F + f];
         dpre[e] = d;
@@ -619,13 +637,13 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_heads_kernel(Scenes sc, co
     }
     __syncthreads();
     for (int e = tid; e < H * nn; e += GAT_T) {
-        const int hd = e / nn, ij = e - hd * nn, i = ij / n, j = ij - i * n;
+        const int hd = dnn(e), ij = e - hd * nn, i = dn(ij), j = ij - i * n;
         const float v = s1[hd * n + i] + s2[hd * n + j];
         dpre[e] = att[e] * (dpre[e] - dot[hd * n + i]) * (v > 0.f ? 1.f : alpha);
     }
     __syncthreads();
     for (int e = tid; e < 2 * Hn; e += GAT_T) {
-        const int hi = e >> 1, hd = hi / n, i = hi - hd * n;
+        const int hi = e >> 1, hd = dn(hi), i = hi - hd * n;
         const float *dp = dpre + hd * nn;
         float acc = 0.f;
         if (e & 1) { for (int k = 0; k < n; ++k) acc += dp[k * n + i]; ds2[hi] = acc; }
@@ -633,7 +651,7 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_heads_kernel(Scenes sc, co
     }
     __syncthreads();
     for (int e = tid; e < n * HF; e += GAT_T) {
-        const int j = e / HF, c = e - j * HF, hd = c / F, f = c - hd * F;
+        const int j = dHF(e), c = e - j * HF, hd = dF(c), f = c - hd * F;
         const float *ah = a + (int64_t)hd * 2 * F;
         float acc = ds1[hd * n + j] * ah[f] + ds2[hd * n + j] * ah[F + f];
         const float *ap = att + hd * nn;
@@ -641,7 +659,7 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_heads_kernel(Scenes sc, co
         dWh[(int64_t)(b + j) * ldg + c] = acc;
     }
     for (int e = tid; e < H * 2 * F; e += GAT_T) {
-        const int hd = e / (2 * F), f = e - hd * 2 * F;
+        const int hd = d2F(e), f = e - hd * 2 * F;
         const float *ds = (f < F ? ds1 : ds2) + hd * n;
         const int ff = f < F ? f : f - F;
         float acc = 0.f;

@@ -401,12 +401,14 @@ struct FastDiv {
 //   s1_i = Wh_i . a[:F], s2_j = Wh_j . a[F:], e_ij = leakyrelu(s1_i + s2_j) where adj_ij > 0, att = softmax_j, out = att Wh (elu)
 // grid (S, H); dynamic LDS: Wh [n][F] | s1 [n] | s2 [n] | att [n][n].  Pair (i,j) and (row, feature) loops are spread over
 // the 64 threads of ONE wave per (scene, head) (single-wave workgroups: barriers cost nothing, many scenes per CU); only the O(n) row normalisations run on n threads.
-__device__ __forceinline__ void gat_logits(int n, int F, int64_t rld, const float *wh, const float *ah, const float *ablk, float alpha,
-                                           float *s1, float *s2, float *att, int tid) {
+// Rows of Wh / dO sit in LDS with a stride FP = 4 ceil(F / 4), zero padded: the n^2 F loops (d att = dO . Wh^T, dWh = att^T dO,
+// out = att Wh) then move float4s - one ds_read_b128 per four multiply-adds instead of two ds_read_b32 per one.
+__device__ __forceinline__ void gat_logits(int n, int F, int FP, int64_t rld, const float *wh, const float *ah, const float *ablk,
+                                           float alpha, float *s1, float *s2, float *att, int tid) {
     for (int e = tid; e < 2 * n; e += GAT_T) {
         const int i = e >> 1, w = e & 1;
         float u = 0.f;
-        for (int f = 0; f < F; ++f) u += wh[i * F + f] * ah[w * F + f];
+        for (int f = 0; f < F; ++f) u += wh[i * FP + f] * ah[w * F + f];
         (w ? s2 : s1)[i] = u;
     }
     __syncthreads();
@@ -435,63 +437,84 @@ __device__ __forceinline__ void gat_logits(int n, int F, int64_t rld, const floa
 __global__ __launch_bounds__(GAT_T) void gat_attn_fwd_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
                                                           int64_t ldw, const float *__restrict__ a, int F, float alpha, int elu,
                                                           float *__restrict__ Out, int64_t ldo) {
-    extern __shared__ float sm[];
+    extern __shared__ __align__(16) float sm[];
     const int s = blockIdx.x, hd = blockIdx.y;
-    const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b;
-    float *wh = sm, *s1 = wh + n * F, *s2 = s1 + n, *att = s2 + n;
+    const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, FP = (F + 3) & ~3, F4 = FP >> 2;
+    float *wh = sm, *s1 = wh + n * FP, *s2 = s1 + n, *att = s2 + n;
     const float *ah = a + (int64_t)hd * 2 * F;
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
-    const FastDiv dF(F);
-    for (int e = tid; e < n * F; e += GAT_T) {
-        const int i = dF(e);
-        wh[e] = Wh[(int64_t)(b + i) * ldw + hd * F + (e - i * F)];
+    const FastDiv dFP(FP), dF4(F4);
+    for (int e = tid; e < n * FP; e += GAT_T) {
+        const int i = dFP(e), f = e - i * FP;
+        wh[e] = f < F ? Wh[(int64_t)(b + i) * ldw + hd * F + f] : 0.f;
     }
     __syncthreads();
-    gat_logits(n, F, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
-    for (int e = tid; e < n * F; e += GAT_T) {
-        const int i = dF(e), f = e - i * F;
-        float acc = 0.f;
-        for (int j = 0; j < n; ++j) acc += att[i * n + j] * wh[j * F + f];
-        if (elu) acc = acc > 0.f ? acc : expm1f(acc);
-        Out[(int64_t)(b + i) * ldo + hd * F + f] = acc;
+    gat_logits(n, F, FP, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
+    const float4 *wh4 = reinterpret_cast<const float4 *>(wh);
+    for (int e = tid; e < n * F4; e += GAT_T) {
+        const int i = dF4(e), q = e - i * F4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < n; ++j) {
+            const float w = att[i * n + j];
+            const float4 v = wh4[j * F4 + q];
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+        float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int f = 4 * q + c;
+            if (f < F) {
+                float v = o[c];
+                if (elu) v = v > 0.f ? v : expm1f(v);
+                Out[(int64_t)(b + i) * ldo + hd * F + f] = v;
+            }
+        }
     }
 }
 
-// backward of the above.  dynamic LDS: Wh [n][F] | dO [n][F] | s1 | s2 | ds1 | ds2 | dot [n] each | att [n][n] | dpre [n][n]
+// backward of the above.  dynamic LDS: Wh [n][FP] | dO [n][FP] | s1 | s2 | ds1 | ds2 | dot [n] each | att [n][n] | dpre [n][n]
 // da_part [S][H x 2F]: this scene's contribution to the gradient of a; the caller sums the column (same-address atomics
 // over thousands of scenes serialise in the L2: 260 us per call before, and the sum order was not fixed).
 __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const float *__restrict__ adj, const float *__restrict__ Wh,
                                                           int64_t ldw, const float *__restrict__ a, int F, float alpha, int elu,
                                                           const float *__restrict__ Out, int64_t ldo, const float *__restrict__ dOut,
                                                           int64_t ldd, float *__restrict__ dWh, int64_t ldg, float *__restrict__ da_part) {
-    extern __shared__ float sm[];
+    extern __shared__ __align__(16) float sm[];
     const int s = blockIdx.x, hd = blockIdx.y;
-    const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b;
-    float *wh = sm, *dO = wh + n * F, *s1 = dO + n * F, *s2 = s1 + n, *ds1 = s2 + n, *ds2 = ds1 + n, *dot = ds2 + n;
+    const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, FP = (F + 3) & ~3, F4 = FP >> 2;
+    float *wh = sm, *dO = wh + n * FP, *s1 = dO + n * FP, *s2 = s1 + n, *ds1 = s2 + n, *ds2 = ds1 + n, *dot = ds2 + n;
     float *att = dot + n, *dpre = att + n * n;
     const float *ah = a + (int64_t)hd * 2 * F;
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
-    const FastDiv dF(F), dn(n);
-    for (int e = tid; e < n * F; e += GAT_T) {
-        const int ii = dF(e);
-        const int64_t row = b + ii;
-        const int col = hd * F + (e - ii * F);
-        wh[e] = Wh[row * ldw + col];
-        float g = dOut[row * ldd + col];
-        if (elu) { const float o = Out[row * ldo + col]; g *= o > 0.f ? 1.f : o + 1.f; }
+    const FastDiv dFP(FP), dF4(F4), dn(n);
+    for (int e = tid; e < n * FP; e += GAT_T) {
+        const int ii = dFP(e), f = e - ii * FP;
+        float w = 0.f, g = 0.f;
+        if (f < F) {
+            const int64_t row = b + ii;
+            const int col = hd * F + f;
+            w = Wh[row * ldw + col];
+            g = dOut[row * ldd + col];
+            if (elu) { const float o = Out[row * ldo + col]; g *= o > 0.f ? 1.f : o + 1.f; }
+        }
+        wh[e] = w;
         dO[e] = g;
     }
     __syncthreads();
-    gat_logits(n, F, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
+    gat_logits(n, F, FP, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
+    const float4 *wh4 = reinterpret_cast<const float4 *>(wh), *dO4 = reinterpret_cast<const float4 *>(dO);
     // d att_ij = dO_i . Wh_j
     for (int e = tid; e < n * n; e += GAT_T) {
         const int i = dn(e), j = e - i * n;
         float d = 0.f;
-        for (int f = 0; f < F; ++f) d += dO[i * F + f] * wh[j * F + f];
+        for (int q = 0; q < F4; ++q) {
+            const float4 u = dO4[i * F4 + q], v = wh4[j * F4 + q];
+            d += (u.x * v.x + u.y * v.y) + (u.z * v.z + u.w * v.w);
+        }
         dpre[e] = d;
     }
     __syncthreads();
@@ -515,17 +538,26 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
         else       { for (int k = 0; k < n; ++k) acc += dpre[i * n + k]; ds1[i] = acc; }
     }
     __syncthreads();
-    for (int e = tid; e < n * F; e += GAT_T) {
-        const int j = dF(e), f = e - j * F;
-        float acc = ds1[j] * ah[f] + ds2[j] * ah[F + f];
-        for (int i = 0; i < n; ++i) acc += att[i * n + j] * dO[i * F + f];
-        dWh[(int64_t)(b + j) * ldg + hd * F + f] = acc;
+    for (int e = tid; e < n * F4; e += GAT_T) {
+        const int j = dF4(e), q = e - j * F4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < n; ++i) {
+            const float w = att[i * n + j];
+            const float4 v = dO4[i * F4 + q];
+            acc.x += w * v.x; acc.y += w * v.y; acc.z += w * v.z; acc.w += w * v.w;
+        }
+        const float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int f = 4 * q + c;
+            if (f < F) dWh[(int64_t)(b + j) * ldg + hd * F + f] = o[c] + ds1[j] * ah[f] + ds2[j] * ah[F + f];
+        }
     }
     for (int f = tid; f < 2 * F; f += GAT_T) {
         const float *ds = f < F ? ds1 : ds2;
         const int ff = f < F ? f : f - F;
         float acc = 0.f;
-        for (int i = 0; i < n; ++i) acc += ds[i] * wh[i * F + ff];
+        for (int i = 0; i < n; ++i) acc += ds[i] * wh[i * FP + ff];
         da_part[((int64_t)s * gridDim.y + hd) * 2 * F + f] = acc;
     }
 }
@@ -919,8 +951,8 @@ extern "C" hipError_t dn_t_bn_bwd(int64_t M, int N, const float *X, int64_t ldx,
 }
 
 extern "C" int64_t dn_t_gat_lds_bytes(int n_max, int F, int backward) {
-    const int64_t n = n_max;
-    return sizeof(float) * (backward ? 2 * n * F + 5 * n + 2 * n * n : n * F + 2 * n + n * n);
+    const int64_t n = n_max, FP = (F + 3) & ~3;          // rows of Wh / dO are padded to float4s in LDS
+    return sizeof(float) * (backward ? 2 * n * FP + 5 * n + 2 * n * n : n * FP + 2 * n + n * n);
 }
 extern "C" hipError_t dn_t_gat_attn_fwd(const int32_t *scene_ptr, const int64_t *off_compact, int S, int n_max, int64_t adj_ld, const float *adj,
                                         const float *Wh, int64_t ldw, const float *a, int H, int F, float alpha, int elu, float *Out,

@@ -22,6 +22,9 @@ def scene_ptr_from_sse(seq_start_end, n_rows: Optional[int] = None) -> np.ndarra
     Scenes must tile the rows contiguously (they do for every loader of the reference:
     models/dagnet/data/loader_bsk.py:12-35, loader_sdd.py:16-42)."""
     if isinstance(seq_start_end, torch.Tensor):
+        if seq_start_end.is_cuda and torch.cuda.is_current_stream_capturing():
+            raise ValueError("under hipGraph capture pass seq_start_end as a host tensor or list "
+                             "(a device tensor would need a blocking copy, which a capturing stream refuses)")
         sse = seq_start_end.detach().cpu().numpy()
     else:
         sse = np.asarray(seq_start_end)

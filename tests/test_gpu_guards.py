@@ -137,3 +137,43 @@ def test_overlapping_calls_on_one_plan_are_refused():
         third = run()
     torch.cuda.synchronize()
     assert float(third[0]) == float(first[0])
+
+
+@pytest.mark.parametrize("kind", ["vrnn", "dagnet"])
+def test_sample_replays_from_a_captured_hip_graph(kind):
+    """sample_k inside torch.cuda.graph: the rollout kernel, the NaN guard and (on workspace-owning plans) the in-flight
+    bookkeeping are all capturable - no allocation, no event query on a capturing stream; the replay reproduces the eager call
+    bit for bit and follows new inputs copied into the static tensors."""
+    kw = dict(vrnn=dict(n_layers=2), dagnet=dict(n_layers=2))[kind]
+    a, m, _ = _model(kind, **kw)
+    K, T = 3, 8
+    obs, gt, obs_rel, gt_rel, og, pg, sse = [t.to(DEV) for t in syn.make_batch(SIZES, 8, T, 3)]
+    N = obs.shape[1]
+    h = (syn.uniform_noise(3, "h0", (a.n_layers, N, 64)) - 0.5).to(DEV)
+    eps = syn.uniform_noise(3, "eps", (K, T, N, a.z_dim)).to(DEV)
+    q = syn.exp1_noise(3, "q", (K, T, N, a.g_dim)).to(DEV)
+    if kind == "dagnet":
+        g = torch.cuda.CUDAGraph()
+        with pytest.raises(ValueError, match="host tensor"), torch.cuda.graph(g):
+            _sample(kind, m, K, T, h, obs, og, sse, eps, q)              # the scene list must not need a blocking copy
+        del g
+    sse = sse.cpu()
+    eager = _sample(kind, m, K, T, h, obs, og, sse, eps, q)
+    torch.cuda.synchronize()
+    h_static = h.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _sample(kind, m, K, T, h_static, obs, og, sse, eps, q)          # plan creation happens outside the capture
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = _sample(kind, m, K, T, h_static, obs, og, sse, eps, q)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
+    h2 = h * 0.5
+    h_static.copy_(h2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, _sample(kind, m, K, T, h2, obs, og, sse, eps, q))

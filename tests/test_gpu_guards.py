@@ -177,3 +177,28 @@ def test_sample_replays_from_a_captured_hip_graph(kind):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, _sample(kind, m, K, T, h2, obs, og, sse, eps, q))
+
+
+def test_forward_replays_from_a_captured_hip_graph():
+    """The teacher-forced forward (eval mode) captures too: losses come back as device scalars, the seed is a launch argument
+    (so a replay repeats its noise - by design of a graph)."""
+    a, m, _ = _model("dagnet", n_layers=2)
+    obs, gt, obs_rel, gt_rel, og, pg, sse = [t.to(DEV) for t in syn.make_batch(SIZES, 8, 4, 3)]
+    sse = sse.cpu()
+    adj = compute_adjs_distsim(a, sse, obs, gt, compact=True)
+    rel = obs_rel.clone()
+    run = lambda: m(obs, rel, og.to(torch.int32), sse, adj, seed=4)  # noqa: E731
+    eager = run()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = run()
+    g.replay()
+    torch.cuda.synchronize()
+    for x, y in zip(out, eager):
+        assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))
+    rel.mul_(0.5)
+    g.replay()
+    torch.cuda.synchronize()
+    for x, y in zip(out, run()):
+        assert torch.equal(torch.as_tensor(x), torch.as_tensor(y))

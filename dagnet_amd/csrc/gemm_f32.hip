@@ -486,6 +486,187 @@ __global__ __launch_bounds__(256, 4) void gemm_tn_kernel(const TnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same product without LDS in the main loop.  The 32x32x2 MFMA wants, from lane (lr, lh), one element of row m + lh of each
+// operand; WHICH column a lane feeds only decides where its result lands.  So lane lr takes the NT consecutive floats at column
+// NT * lr of A (one dwordxNT buffer load: a wave-load covers two whole rows) and the KT floats at column KT * lr of B, and output
+// tile (cn, ck) holds the columns {NT * i + cn} x {KT * j + ck}.  Every wave streams its own row range straight from HBM into MFMA
+// operands - no staging stores, no barriers - with the loads of the next block of 2 * P rows in flight under the current block's
+// MFMAs.  Each load has its own descriptor (base and remaining bytes advance in SGPRs), so the hardware range check zeroes whatever
+// lies beyond the wave's rows and the loop needs no tail code.  The four waves of a workgroup then add their tiles through LDS
+// in a fixed order and write one partial like gemm_tn_kernel does.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+__device__ float gd_load1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ f32x2 gd_load2(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v2f32");
+__device__ f32x3 gd_load3(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v3f32");
+
+template <int NV>
+__device__ __forceinline__ void gd_load(float (&d)[NV], const i32x4 r, const int vo) {
+    static_assert(NV == 1 || NV == 2 || NV == 3 || NV == 4 || NV == 6, "columns per lane");
+    if constexpr (NV == 1) d[0] = gd_load1(r, vo, 0, 0);
+    if constexpr (NV == 2) { const f32x2 t = gd_load2(r, vo, 0, 0); d[0] = t[0]; d[1] = t[1]; }
+    if constexpr (NV == 3) { const f32x3 t = gd_load3(r, vo, 0, 0); d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; }
+    if constexpr (NV == 4) { const f32x4 t = gp_load4(r, vo, 0, 0); d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = t[3]; }
+    if constexpr (NV == 6) {
+        const f32x3 t = gd_load3(r, vo, 0, 0), u = gd_load3(r, vo + 12, 0, 0);
+        d[0] = t[0]; d[1] = t[1]; d[2] = t[2]; d[3] = u[0]; d[4] = u[1]; d[5] = u[2];
+    }
+}
+
+constexpr int tnd_wpc(int NT, int KT) {           // register budget in workgroups per CU: accumulators + two operand blocks + addresses
+    const int regs = 16 * NT * KT + 16 * (NT + KT) + 24;
+    return regs <= 128 ? 4 : (regs <= 168 ? 3 : (regs <= 256 ? 2 : 1));
+}
+
+// NH = 2: the output columns are split in two halves of 32 * NT; waves 0-1 take the first and waves 2-3 the second half over the
+// SAME rows, so B is fetched from HBM once and the second fetch is served by the cache (N = 192: the GRU's gate columns).
+template <int NT, int KT, int NH>
+__global__ __launch_bounds__(256, tnd_wpc(NT, KT)) void gemm_tn_direct_kernel(const TnArgs p) {
+    constexpr int P = 8;                                    // row pairs per operand block
+    constexpr int NP = 32 * NT * NH, KP = 32 * KT, WS = 4 / NH;   // WS: waves that share a column half (they split the rows)
+    extern __shared__ float tsm[];                          // [NP][KP] tile sums, then [WS][NP] bias sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    const int half = wave / WS, sub = wave % WS, nh = p.N / NH;     // nh: columns per half
+    const int mbeg = blockIdx.x * p.rows_per_split, mend = min(p.M, mbeg + p.rows_per_split);
+    const int q = ((p.rows_per_split + WS - 1) / WS + 1) & ~1;      // rows per wave (even)
+    const int w0 = __builtin_amdgcn_readfirstlane(min(mend, mbeg + sub * q));
+    const int w1 = __builtin_amdgcn_readfirstlane(min(mend, w0 + q));
+    const int64_t lda4 = p.lda * 4, ldb4 = p.ldb * 4;
+    const int voa = NT * lr < nh ? (int)(lh * lda4) + (half * nh + NT * lr) * 4 : (int)0x80000000;     // a lane without columns reads zeros
+    const int vob = KT * lr < p.K ? (int)(lh * ldb4) + KT * lr * 4 : (int)0x80000000;
+    const bool want_bias = p.bias_part != nullptr;
+    float a0[P][NT], b0[P][KT], a1[P][NT], b1[P][KT];
+    f32x16 acc[NT][KT];
+    float bs[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        bs[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < KT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    }
+    auto load = [&](float (&a)[P][NT], float (&b)[P][KT], const int row) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int r = row + 2 * i;
+            gd_load<NT>(a[i], gp_rsrc(p.A + (int64_t)r * p.lda, (int64_t)(w1 - r) * lda4), voa);
+            gd_load<KT>(b[i], gp_rsrc(p.B + (int64_t)r * p.ldb, (int64_t)(w1 - r) * ldb4), vob);
+        }
+    };
+    auto mult = [&](const float (&a)[P][NT], const float (&b)[P][KT]) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+#pragma unroll
+            for (int cn = 0; cn < NT; ++cn) {
+#pragma unroll
+                for (int ck = 0; ck < KT; ++ck) acc[cn][ck] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][cn], b[i][ck], acc[cn][ck], 0, 0, 0);
+                if (want_bias) bs[cn] += a[i][cn];
+            }
+        }
+    };
+    load(a0, b0, w0);
+    for (int row = w0; row < w1; row += 4 * P) {
+        load(a1, b1, row + 2 * P);
+        mult(a0, b0);
+        load(a0, b0, row + 4 * P);
+        mult(a1, b1);
+    }
+    // the waves of a column half add their tiles in wave order
+    for (int w = 0; w < WS; ++w) {
+        if (sub == w) {
+#pragma unroll
+            for (int cn = 0; cn < NT; ++cn)
+#pragma unroll
+                for (int ck = 0; ck < KT; ++ck)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int loc = NT * (4 * lh + (r & 3) + 8 * (r >> 2)) + cn, k = KT * lr + ck;
+                        float *d = tsm + (half * nh + loc) * KP + k;
+                        if (loc < nh) *d = w == 0 ? acc[cn][ck][r] : *d + acc[cn][ck][r];    // rows beyond a half belong to the next one
+                    }
+        }
+        __syncthreads();
+    }
+    float *C = p.C + (int64_t)blockIdx.x * p.N * p.ldc;
+    for (int i = tid; i < p.N * KP; i += 256) {
+        const int n = i / KP, k = i % KP;
+        if (k < p.K) {
+            float *dst = C + (int64_t)n * p.ldc + k;
+            *dst = p.part_accumulate ? *dst + tsm[i] : tsm[i];
+        }
+    }
+    if (want_bias) {
+        __syncthreads();
+#pragma unroll
+        for (int cn = 0; cn < NT; ++cn) {
+            const float t = bs[cn] + __shfl_xor(bs[cn], 32);
+            if (lh == 0 && NT * lr < nh) tsm[sub * NP + half * nh + NT * lr + cn] = t;
+        }
+        __syncthreads();
+        if (tid < p.N) {
+            float t = tsm[tid];
+#pragma unroll
+            for (int w = 1; w < WS; ++w) t += tsm[w * NP + tid];
+            float *bp = p.bias_part + (int64_t)blockIdx.x * p.N + tid;
+            *bp = p.part_accumulate ? *bp + t : t;
+        }
+    }
+}
+
+// columns per lane for an operand (or operand half) of `n` columns (0: the direct kernel does not take it)
+static int tnd_cols(int n, int64_t ld) {
+    const int v = (n + 31) / 32;
+    if (v < 1 || v > 3 || n % v != 0) return 0;
+    if (v == 2 && (ld & 1)) return 0;
+    return v;
+}
+
+// X(NT, KT, NH): the instantiations (NH = 2 above 96 output columns)
+#define DN_TND_LIST X(1, 1, 1) X(1, 2, 1) X(1, 3, 1) X(2, 1, 1) X(2, 2, 1) X(2, 3, 1) X(3, 1, 1) X(3, 2, 1) X(3, 3, 1) \
+                    X(2, 1, 2) X(2, 2, 2) X(3, 1, 2) X(3, 2, 2)
+static size_t tnd_lds(int nt, int kt, int nh) { return sizeof(float) * std::max(32 * nt * nh * 32 * kt, 4 * 32 * nt * nh); }
+
+// workgroups of one instantiation that are resident at once (what its registers and LDS allow on this device): the number of splits,
+// so that one round of workgroups covers the rows; 0 = no such instantiation
+static int tnd_resident(int nt, int kt, int nh) {
+#define X(NT_, KT_, NH_)                                                                                                        \
+    if (nt == NT_ && kt == KT_ && nh == NH_) {                                                                                \
+        static const int n = [] {                                                                                             \
+            int per_cu = 0, dev = 0, cus = 256;                                                                               \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_tn_direct_kernel<NT_, KT_, NH_>, 256,              \
+                                                             tnd_lds(NT_, KT_, NH_)) != hipSuccess || per_cu < 1)             \
+                per_cu = tnd_wpc(NT_, KT_);                                                                                   \
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256; \
+            return std::min(per_cu, 4) * (cus > 0 ? cus : 256);                                                               \
+        }();                                                                                                                  \
+        return n;                                                                                                             \
+    }
+    DN_TND_LIST
+#undef X
+    return 0;
+}
+
+static bool launch_tn_direct(const TnArgs &a, int splits, hipStream_t st) {
+    const int nhalves = a.N > 96 ? 2 : 1;
+    if (a.N % nhalves) return false;
+    const int nt = tnd_cols(a.N / nhalves, a.lda), kt = tnd_cols(a.K, a.ldb);
+    if (!nt || !kt || a.bidx || a.lda * 4 * 2 >= 0x7fffffffLL || a.ldb * 4 * 2 >= 0x7fffffffLL) return false;
+    if (nhalves == 2 && nt == 2 && ((a.N / 2) & 1)) return false;
+    if (nt == 2 && (reinterpret_cast<uintptr_t>(a.A) & 7)) return false;
+    if (kt == 2 && (reinterpret_cast<uintptr_t>(a.B) & 7)) return false;
+#define X(NT_, KT_, NH_)                                                                                                        \
+    if (nt == NT_ && kt == KT_ && nhalves == NH_) {                                                                           \
+        hipLaunchKernelGGL((gemm_tn_direct_kernel<NT_, KT_, NH_>), dim3(splits), dim3(256), tnd_lds(NT_, KT_, NH_), st, a);   \
+        return true;                                                                                                          \
+    }
+    DN_TND_LIST
+#undef X
+    return false;
+}
+
 // out[r][c] (+)= sum_s part[s][r][c]   (deterministic second pass of the split reduction; out has row stride ldc)
 // block = 32 outputs x 32 split lanes: coalesced 128-byte reads, fixed summation order
 __global__ __launch_bounds__(1024) void reduce_splits_kernel(const float *part, int splits, int N, int K, float *out, int64_t ldc,
@@ -599,6 +780,12 @@ extern "C" hipError_t dn_gemm_nt(const float *A, int64_t lda, const float *W, in
 extern "C" int64_t dn_gemm_tn_splits(int M, int N, int K) {
     const int64_t blocks = (int64_t)((N + 63) / 64) * ((K + 63) / 64);
     int64_t s = (1024 + blocks - 1) / blocks;
+    {   // shapes of the direct kernel: one workgroup per split, as many as are resident at once
+        static const bool off = getenv("DAGNET_NO_TN_DIRECT") != nullptr;
+        const int nh = N > 96 ? 2 : 1, nt = (N / nh + 31) / 32, kt = (K + 31) / 32;
+        const int res = off ? 0 : gemm::tnd_resident(nt, kt, nh);
+        if (res > 0) s = res;
+    }
     const int64_t cap = (M + 127) / 128;
     if (s > cap) s = cap;
     return s < 1 ? 1 : (s > 1024 ? 1024 : s);
@@ -619,7 +806,9 @@ extern "C" hipError_t dn_gemm_tn_staged(const float *A, int64_t lda, const float
     if (stages & 1) {
         gemm::TnArgs a{A, lda, B, ldb, part, K, M, N, K, rows, bidx, bias_part, part_accumulate};
         const int blocks = ((N + 63) / 64) * ((K + 63) / 64);
-        hipLaunchKernelGGL(gemm::gemm_tn_kernel, dim3(blocks, splits), dim3(256), 0, st, a);
+        static const bool no_direct = getenv("DAGNET_NO_TN_DIRECT") != nullptr;
+        if (no_direct || !gemm::launch_tn_direct(a, splits, st))
+            hipLaunchKernelGGL(gemm::gemm_tn_kernel, dim3(blocks, splits), dim3(256), 0, st, a);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }

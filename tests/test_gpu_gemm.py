@@ -61,6 +61,33 @@ def test_gemm_matches_torch(M, N, K, transb):
     torch.testing.assert_close(C.double(), want, **tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(40960, 64, 64), (5001, 192, 64), (2049, 32, 64), (3000, 64, 32), (7001, 90, 90), (4100, 90, 64),
+                                   (2500, 90, 32), (2100, 32, 90), (3333, 64, 20), (2048, 2, 64), (2300, 64, 2), (100, 64, 64), (31, 50, 64),
+                                   (3000, 33, 64), (2600, 64, 130), (2200, 128, 64), (1, 64, 64), (2500, 160, 64), (9000, 96, 96)])
+def test_gemm_tn_matches_torch(M, N, K):
+    """Weight-gradient product C[N,K] = A^T B with the bias gradient from the same pass: the LDS-free kernel (<= 3 x 3 and 6 x 2 column
+    groups of 32 whose widths divide evenly) and the tiled one behind it, padded rows holding NaN, odd row counts, accumulate."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A, B = _padded(M, N, g), _padded(M, K, g)
+    ref = A.double().t() @ B.double()
+    tol = dict(rtol=2e-5, atol=2e-5 * M ** 0.5)
+    Cw = torch.full((N, K), float("nan"), device=DEV)
+    db = torch.full((N,), float("nan"), device=DEV)
+    _ops.gemm_tn(A, B, Cw, dbias=db)
+    torch.testing.assert_close(Cw.double(), ref, **tol)
+    torch.testing.assert_close(db.double(), A.double().sum(0), **tol)
+    C0, b0 = Cw.clone(), db.clone()
+    _ops.gemm_tn(A, B, Cw, accumulate=True, dbias=db)
+    torch.testing.assert_close(Cw.double(), 2 * C0.double(), **tol)
+    torch.testing.assert_close(db.double(), 2 * b0.double(), **tol)
+    C2 = torch.empty((N, K), device=DEV)
+    _ops.gemm_tn(A, B, C2)                                              # without the bias sums; and bit-reproducible
+    assert torch.equal(C2, C0)
+    Ac, Bc = A.contiguous(), B.contiguous()                            # unpadded row strides (90, 50, 33, 2 ...)
+    _ops.gemm_tn(Ac, Bc, C2)
+    torch.testing.assert_close(C2.double(), ref, **tol)
+
+
 def test_gemm_unpadded_rows_take_the_tiled_kernel():
     """Contiguous [M, 90] operands (row stride not a multiple of 4) are not eligible for the skinny kernel: same answer."""
     g = torch.Generator().manual_seed(5)

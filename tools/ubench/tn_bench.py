@@ -1,36 +1,42 @@
-"""Times the weight-gradient GEMM (dagnet_op_gemm_tn_partial) and the narrow forward GEMM alone, at the training bench's shapes.
-    python tools/ubench/tn_bench.py"""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-import torch
-from dagnet_amd import _ops
-from dagnet_amd._ops import _lib, _m, _p, _stream
+"""Time dagnet_op_gemm_tn (weight gradients, C[N,K] = A[M,N]^T B[M,K]) at the training step's stacked shapes (M = steps x rows),
+operands rotated through several buffers so they come from HBM.
+    python tools/ubench/tn_bench.py [M]"""
+import os
+import sys
 
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from dagnet_amd import _ops  # noqa: E402
+
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 49 * 40960
 dev = "cuda:0"
-M = 81920
-lib = _lib()
-for N, K in ((64, 64), (64, 128), (192, 128), (96, 64)):
-    A = torch.randn(M, N, device=dev)
-    B = torch.randn(M, K, device=dev)
-    part = torch.empty(int(lib.dagnet_op_gemm_tn_workspace(M, N, K)), device=dev)
-    (a, lda), (b, ldb) = _m(A, "A"), _m(B, "B")
-    def run(first):
-        lib.dagnet_op_gemm_tn_partial(a, lda, b, ldb, None, 1, M, N, K, _p(part), first, _stream(A.device))
-    for first in (1, 0):
-        for _ in range(3): run(first)
-        torch.cuda.synchronize()
+NB = 3
+
+
+def bench(fn, reps=4):
+    fn(0)
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20): run(first)
-        e1.record(); torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
-        print(f"gemm_tn partial M={M} N={N} K={K} first={first}: {us:.1f} us, {(M*(N+K)*4)/us/1e6:.2f} TB/s of inputs, {2*M*N*K/us/1e6:.1f} TFLOP/s")
-    W = torch.randn(N, K, device=dev); C = torch.empty(M, N, device=dev)
-    for _ in range(3): _ops.gemm(B, W, C)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(20): _ops.gemm(B, W, C)
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / 20 * 1e3
-    print(f"gemm_nt M={M} N={N} K={K}: {us:.1f} us, {(M*(N+K)*4)/us/1e6:.2f} TB/s, {2*M*N*K/us/1e6:.1f} TFLOP/s")
+        for i in range(NB):
+            fn(i)
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / NB * 1e3)
+    return best
+
+
+for (N, K, bias) in ((64, 64, True), (64, 64, False), (192, 64, True), (64, 128, True), (64, 32, True), (32, 64, True), (96, 64, True),
+                     (64, 92, True), (8, 64, False), (64, 2, True)):
+    A = [torch.randn((M, N), device=dev) for _ in range(NB)]
+    B = [torch.randn((M, K), device=dev) for _ in range(NB)]
+    Cw = torch.empty((N, K), device=dev)
+    db = torch.empty(N, device=dev) if bias else None
+    t = bench(lambda i: _ops.gemm_tn(A[i], B[i], Cw, dbias=db))
+    byt = 4 * M * (N + K)
+    fl = 2.0 * M * N * K
+    print(f"M={M} N={N} K={K} bias={int(bias)}: {t:8.1f} us  {byt / t / 1e6:6.2f} TB/s  {fl / t / 1e6:6.1f} TFLOP/s", flush=True)
+    del A, B

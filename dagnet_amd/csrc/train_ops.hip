@@ -312,6 +312,56 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(int64_t M, int N, int r
     }
 }
 
+// The same for 16-byte rows (N and the row strides multiples of 4, aligned bases): a thread owns four columns and every fourth
+// row lane-group, a wave-load covers four rows of 64 columns, 16 rows in flight per wave and operand.  (The scalar form keeps
+// 3 KB in flight per wave: the BatchNorm backward statistics ran at 1.2 TB/s.)
+template <int MODE>
+__global__ __launch_bounds__(256) void col_reduce4_kernel(int64_t M, int N, int rows_per_split, const float *__restrict__ X, int64_t ldx,
+                                                          const float *__restrict__ stat, const float *__restrict__ dOut, int64_t ldd,
+                                                          const float *__restrict__ Out, int64_t ldo, int tanh_out,
+                                                          float *__restrict__ part) {
+    __shared__ float red[2][16][64 + 4];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cl * 4;
+    const int64_t m0 = (int64_t)blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
+    float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+        float4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
+        if (MODE >= 1) mu = *reinterpret_cast<const float4 *>(stat + c);
+        if (MODE == 2) is = *reinterpret_cast<const float4 *>(stat + N + c);
+#pragma unroll 4
+        for (int64_t m = m0 + rl; m < m1; m += 16) {
+            const float4 x = *reinterpret_cast<const float4 *>(X + m * ldx + c);
+            if (MODE == 0) { q0.x += x.x; q0.y += x.y; q0.z += x.z; q0.w += x.w; }
+            else if (MODE == 1) {
+                const float d0 = x.x - mu.x, d1 = x.y - mu.y, d2 = x.z - mu.z, d3 = x.w - mu.w;
+                q0.x += d0 * d0; q0.y += d1 * d1; q0.z += d2 * d2; q0.w += d3 * d3;
+            } else {
+                float4 g = *reinterpret_cast<const float4 *>(dOut + m * ldd + c);
+                if (tanh_out) {
+                    const float4 o = *reinterpret_cast<const float4 *>(Out + m * ldo + c);
+                    g.x *= 1.0f - o.x * o.x; g.y *= 1.0f - o.y * o.y; g.z *= 1.0f - o.z * o.z; g.w *= 1.0f - o.w * o.w;
+                }
+                q0.x += g.x; q0.y += g.y; q0.z += g.z; q0.w += g.w;
+                q1.x += g.x * (x.x - mu.x) * is.x; q1.y += g.y * (x.y - mu.y) * is.y;
+                q1.z += g.z * (x.z - mu.z) * is.z; q1.w += g.w * (x.w - mu.w) * is.w;
+            }
+        }
+    }
+    *reinterpret_cast<float4 *>(&red[0][rl][cl * 4]) = q0;
+    *reinterpret_cast<float4 *>(&red[1][rl][cl * 4]) = q1;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+        const int q = threadIdx.x >> 6, l = threadIdx.x & 63, col = blockIdx.x * 64 + l;
+        if (col < N) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += red[q][r][l];
+            part[((int64_t)blockIdx.y * 2 + q) * N + col] = t;
+        }
+    }
+}
+
 // stage 2: out_q[c] (+)= scale * sum_split part[split][q][c]; one wave per column, lanes stride over the splits
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -871,8 +921,13 @@ static hipError_t col_reduce(int64_t M, int N, const float *X, int64_t ldx, cons
                              int accumulate, hipStream_t st) {
     const int splits = col_splits(M);
     const int rows = (int)((M + splits - 1) / splits);
-    hipLaunchKernelGGL((tops::col_reduce_kernel<MODE>), dim3((N + 63) / 64, splits), dim3(256), 0, st, M, N, rows, X, ldx, stat, dOut, ldd,
-                       Out, ldo, tanh_out, part);
+    auto al = [](const float *q, int64_t ld) { return !q || (((reinterpret_cast<uintptr_t>(q) & 15) == 0) && (ld & 3) == 0); };
+    if ((N & 3) == 0 && al(X, ldx) && al(stat, 0) && (MODE < 2 || (al(dOut, ldd) && (!tanh_out || al(Out, ldo)))))
+        hipLaunchKernelGGL((tops::col_reduce4_kernel<MODE>), dim3((N + 63) / 64, splits), dim3(256), 0, st, M, N, rows, X, ldx, stat, dOut,
+                           ldd, Out, ldo, tanh_out, part);
+    else
+        hipLaunchKernelGGL((tops::col_reduce_kernel<MODE>), dim3((N + 63) / 64, splits), dim3(256), 0, st, M, N, rows, X, ldx, stat, dOut,
+                           ldd, Out, ldo, tanh_out, part);
     hipLaunchKernelGGL(tops::col_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, splits, part, scale, out0, out1, accumulate);
     return hipGetLastError();
 }

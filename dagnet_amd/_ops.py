@@ -361,7 +361,6 @@ def flush_products(items, dst, bias, accumulate):
         Mt = n * M
         a_ptr = C.c_void_p(base[0].data_ptr())
         acc = int(bool(accumulate) or i > 0)
-        if os.environ.get('DAGNET_TN_LOG'): print('TN', Mt, N, K, lda, ldb, B is None, bias is not None, flush=True)
         if B is not None:
             ws = _ws(A.device, lib.dagnet_op_gemm_tn_workspace(Mt, N, K))
             _check(lib.dagnet_op_gemm_tn(a_ptr, lda, C.c_void_p(base[1].data_ptr()), ldb, c, ldc, _p(bias), Mt, N, K, _p(ws), acc,

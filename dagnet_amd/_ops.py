@@ -22,7 +22,7 @@ ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
 OP_EXPORTS = (
     "dagnet_op_gemm", "dagnet_op_gemm_dact", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
-    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd",
+    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
     "dagnet_op_gat_attn_fwd", "dagnet_op_gat_attn_bwd", "dagnet_op_adj_matmul", "dagnet_op_disposition", "dagnet_op_sumsq",
@@ -51,6 +51,7 @@ def _lib():
         lib.dagnet_op_softmax_bwd.argtypes = [i64, i32, vp, i64, vp, i64, vp, i64, vp]
         lib.dagnet_op_gru_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_gru_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+        lib.dagnet_op_gru_layer_fwd.argtypes = [i64, i32, vp, i64, i32, vp, i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_vae_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_vae_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp]
         lib.dagnet_op_nll_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp]
@@ -431,6 +432,9 @@ def _empty(M, N, like):
 # ---------------------------------------------------------------------------------------------
 # dense layers
 # ---------------------------------------------------------------------------------------------
+_LAZY_LINEAR = False         # set by gru_step around the two gate products whose values the fused layer kernel produces itself
+
+
 class LinearFn(torch.autograd.Function):
     """y = act(sum_s x_s W[:, c_s : c_s + K_s]^T + b + W[:, gcol + gidx])  -- an nn.Linear whose input is the
     concatenation of dense pieces and (optionally) one one-hot piece given by its index (never materialised)."""
@@ -443,7 +447,7 @@ class LinearFn(torch.autograd.Function):
         y = POOL.at(ctx.slot, "y", (M, N), xs[0])
         ctx.gaccs = [_gacc_of(x) for x in xs]
         last = len(xs) - 1
-        for s, (x, c0) in enumerate(zip(xs, cols)):
+        for s, (x, c0) in enumerate(() if _LAZY_LINEAR else zip(xs, cols)):       # lazy: the consumer computes y (GruLayerFn)
             Ks = x.shape[1]
             Wp = W[:, c0:c0 + Ks]
             fin = s == last
@@ -658,6 +662,34 @@ class SoftmaxFn(torch.autograd.Function):
         (yp, ldy), (gp, ldg), (xp, ldx) = _m(y), _m(dy), _m(dx)
         _check(_lib().dagnet_op_softmax_bwd(y.shape[0], y.shape[1], yp, ldy, gp, ldg, xp, ldx, _stream(y.device)))
         return dx
+
+
+class GruLayerFn(torch.autograd.Function):
+    """h' of one GRU layer step computed from the layer's INPUTS by dagnet_op_gru_layer_fwd (one kernel for rnn_dim 64:
+    csrc/gru_fused.hip).  gi and gh are the outputs of the two gate products' LinearFn nodes, created lazily (allocated, not
+    computed): they keep the autograd graph - and with it the whole backward pass (GruCellFn's gate gradients, then the
+    products' input and weight gradients) - exactly as in the unfused form."""
+
+    @staticmethod
+    def forward(ctx, gi, gh, h, Wih, bih, Whh, bhh, *xs):
+        M, R = h.shape
+        ctx.slot = POOL.site()
+        hn = POOL.at(ctx.slot, "hn", (M, R), h)
+        gates = POOL.at(ctx.slot, "gates", (M, 3 * R), h)
+        (x0, ldx0) = _m(xs[0], "x0")
+        (x1, ldx1) = _m(xs[1], "x1") if len(xs) > 1 else (None, 0)
+        (hp, ldh), (wi, ldwi), (wh, ldwh) = _m(h, "h"), _m(Wih, "W_ih"), _m(Whh, "W_hh")
+        if not (gi.is_contiguous() and gh.is_contiguous()):
+            raise DagnetHipError("gate buffers must be contiguous")
+        _check(_lib().dagnet_op_gru_layer_fwd(M, R, x0, ldx0, xs[0].shape[1], x1, ldx1, xs[1].shape[1] if len(xs) > 1 else 0, hp, ldh,
+                                              wi, ldwi, _p(bih), wh, ldwh, _p(bhh), _p(gi), _p(gh), _p(hn), _p(gates), _stream(h.device)))
+        ctx.save_for_backward(gates, gh, h)
+        ctx.n_extra = 4 + len(xs)
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn):
+        return (*GruCellFn.backward(ctx, dhn), *([None] * ctx.n_extra))
 
 
 class GruCellFn(torch.autograd.Function):
@@ -1007,12 +1039,22 @@ def gru_step(rnn: torch.nn.GRU, xs, cols, h_layers):
     for l in range(rnn.num_layers):
         Wih, Whh = getattr(rnn, f"weight_ih_l{l}"), getattr(rnn, f"weight_hh_l{l}")
         bih, bhh = getattr(rnn, f"bias_ih_l{l}"), getattr(rnn, f"bias_hh_l{l}")
-        if l == 0:
-            gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, tuple(cols), None, 0, 0, *xs)
+        pieces, pcols = (list(xs), tuple(cols)) if l == 0 else ([out[-1]], (0,))
+        contiguous_cols = all(c == sum(x.shape[1] for x in pieces[:i]) for i, c in enumerate(pcols))
+        if len(pieces) <= 2 and contiguous_cols:
+            global _LAZY_LINEAR
+            _LAZY_LINEAR = True       # the two products are only recorded; GruLayerFn computes their values (and the cell) itself
+            try:
+                gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, pcols, None, 0, 0, *pieces)
+                gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, 0, h_layers[l])
+            finally:
+                _LAZY_LINEAR = False
+            hn = GruLayerFn.apply(gi, gh, h_layers[l], Wih, bih, Whh, bhh, *pieces)
         else:
-            gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, (0,), None, 0, 0, out[-1])
-        gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, 0, h_layers[l])
-        out.append(fanout(GruCellFn.apply(gi, gh, h_layers[l])))      # read by the next layer, the next step, the graph, ...
+            gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, pcols, None, 0, 0, *pieces)
+            gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, 0, h_layers[l])
+            hn = GruCellFn.apply(gi, gh, h_layers[l])
+        out.append(fanout(hn))      # read by the next layer, the next step, the graph, ...
     return out
 
 

@@ -1655,6 +1655,34 @@ extern "C" int dagnet_op_gru_fwd(int64_t M, int32_t R, const float *gi, const fl
     HIP_TRY(dn_t_gru_fwd(M, R, gi, gh, h, hn, gates, OP_ST));
     return DAGNET_OK;
 }
+extern "C" hipError_t dn_gru_fused_fwd(int64_t M, int R, int npieces, const float *x0, int64_t ldx0, const float *x1, int64_t ldx1,
+                                       const float *h, int64_t ldh, const float *Wih, int64_t ldwih, const float *bih, const float *Whh,
+                                       int64_t ldwhh, const float *bhh, float *hn, int64_t ldhn, float *gates, int64_t ldg, float *gh,
+                                       int64_t ldgh, hipStream_t st);
+// One GRU layer step from its inputs.  The fused kernel (csrc/gru_fused.hip: rnn_dim 64, one or two 64-wide input pieces, >= 2048
+// rows) leaves gi untouched and writes only the n-gate columns of gh; any other shape runs as products + cell and fills both.
+extern "C" int dagnet_op_gru_layer_fwd(int64_t M, int32_t R, const float *x0, int64_t ldx0, int32_t K0, const float *x1, int64_t ldx1,
+                                       int32_t K1, const float *h, int64_t ldh, const float *Wih, int64_t ldwih, const float *bih,
+                                       const float *Whh, int64_t ldwhh, const float *bhh, float *gi, float *gh, float *hn, float *gates,
+                                       void *stream) {
+    OP_NEED(M >= 0 && R >= 1 && K0 >= 1 && K1 >= 0 && M < 0x7fffffffLL, "bad argument");
+    if (M == 0) return DAGNET_OK;
+    OP_NEED(x0 && (K1 == 0 || x1) && h && Wih && Whh && gi && gh && hn && gates, "null operand");
+    static const bool no_fused = getenv("DAGNET_NO_GRU_FUSED") != nullptr;
+    if (!no_fused && K0 == 64 && (K1 == 0 || K1 == 64)) {
+        const hipError_t e = dn_gru_fused_fwd(M, R, K1 ? 2 : 1, x0, ldx0, x1, ldx1, h, ldh, Wih, ldwih, bih, Whh, ldwhh, bhh, hn, R, gates,
+                                              3 * R, gh, 3 * R, OP_ST);
+        if (e == hipSuccess) return DAGNET_OK;
+        if (e != hipErrorNotSupported) HIP_TRY(e);
+    }
+    HIP_TRY(dn_gemm(x0, ldx0, Wih, ldwih, 0, K1 ? nullptr : bih, gi, 3 * R, (int)M, 3 * R, K0, 0, 0.f, 0, nullptr, nullptr, 0, 0, OP_ST));
+    if (K1)
+        HIP_TRY(dn_gemm(x1, ldx1, Wih + K0, ldwih, 0, bih, gi, 3 * R, (int)M, 3 * R, K1, 0, 0.f, 1, nullptr, nullptr, 0, 0, OP_ST));
+    HIP_TRY(dn_gemm(h, ldh, Whh, ldwhh, 0, bhh, gh, 3 * R, (int)M, 3 * R, R, 0, 0.f, 0, nullptr, nullptr, 0, 0, OP_ST));
+    OP_NEED(ldh == R, "the unfused GRU cell needs a contiguous hidden state");
+    HIP_TRY(dn_t_gru_fwd(M, R, gi, gh, h, hn, gates, OP_ST));
+    return DAGNET_OK;
+}
 extern "C" int dagnet_op_gru_bwd(int64_t M, int32_t R, const float *dhn, const float *gates, const float *gh, const float *h, float *dgi,
                                  float *dgh, float *dh, void *stream) {
     OP_NEED(M >= 0 && R >= 1 && (M == 0 || (dhn && gates && gh && h && dgi && dgh && dh)), "bad argument");

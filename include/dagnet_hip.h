@@ -235,6 +235,13 @@ int dagnet_op_softmax_bwd(int64_t M, int32_t N, const float *Y, int64_t ldy, con
 /* Replaces: the gate arithmetic of nn.GRU (models/dagnet/model.py:116,185); gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh
  * [M,3R] come from dagnet_op_gemm.  gates [M,3R] keeps r, z, n for the backward. */
 int dagnet_op_gru_fwd(int64_t M, int32_t R, const float *gi, const float *gh, const float *h, float *hn, float *gates, void *stream);
+/* Replaces: one layer of nn.GRU at seq_len = 1 from its inputs (models/dagnet/model.py:109-110,:186): gi = [x0 | x1] W_ih^T + b_ih,
+ * gh = h W_hh^T + b_hh and the gate arithmetic in one call (x1 = NULL, K1 = 0: a single input piece).  gi, gh [M,3R], hn [M,R],
+ * gates [M,3R] are contiguous.  rnn_dim 64 with 64-wide pieces and >= 2048 rows runs as ONE kernel (csrc/gru_fused.hip) that
+ * leaves gi untouched and writes only columns 2R..3R of gh - all that dagnet_op_gru_bwd reads; other shapes fill both. */
+int dagnet_op_gru_layer_fwd(int64_t M, int32_t R, const float *x0, int64_t ldx0, int32_t K0, const float *x1, int64_t ldx1, int32_t K1,
+                            const float *h, int64_t ldh, const float *Wih, int64_t ldwih, const float *bih, const float *Whh,
+                            int64_t ldwhh, const float *bhh, float *gi, float *gh, float *hn, float *gates, void *stream);
 int dagnet_op_gru_bwd(int64_t M, int32_t R, const float *dhn, const float *gates, const float *gh, const float *h, float *dgi,
                       float *dgh, float *dh, void *stream);
 /* Replaces: _reparameterize + _kld (models/dagnet/model.py:118-128): z = eps exp(logvar_e / 2) + mean_e, kld_row[m] =

@@ -146,3 +146,33 @@ def test_softmax_op_matches_torch(M, N, padded):
     _ops._check(lib.dagnet_op_softmax_bwd(M, N, yp, ldy, gp, ldg, dp, ldd, _ops._stream(x.device)))
     yd, gd = y.double(), dy.double()
     torch.testing.assert_close(dx.double(), yd * (gd - (gd * yd).sum(1, keepdim=True)), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("M,pieces", [(4100, (64, 64)), (2500, (64,)), (100, (64, 64)), (3000, (20, 64)), (40960, (64, 64))])
+def test_gru_layer_matches_torch(M, pieces):
+    """dagnet_op_gru_layer_fwd (one kernel for 64-wide pieces and >= 2048 rows, products + cell otherwise) against the GRU equations
+    in fp64: h', the saved gates and the hidden part of the n gate (all that the backward pass reads)."""
+    import ctypes
+    g = torch.Generator().manual_seed(M + sum(pieces))
+    R, K = 64, sum(pieces)
+    xs = [torch.randn((M, k), generator=g).to(DEV) for k in pieces]
+    h = torch.randn((M, R), generator=g).to(DEV)
+    Wih, Whh = (torch.randn((3 * R, K), generator=g) / K ** 0.5).to(DEV), (torch.randn((3 * R, R), generator=g) / 8).to(DEV)
+    bih, bhh = torch.randn(3 * R, generator=g).to(DEV), torch.randn(3 * R, generator=g).to(DEV)
+    gi = torch.full((M, 3 * R), float("nan"), device=DEV)
+    gh = torch.full((M, 3 * R), float("nan"), device=DEV)
+    hn, gates = torch.empty((M, R), device=DEV), torch.empty((M, 3 * R), device=DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+    x1 = xs[1] if len(xs) > 1 else None
+    _ops._check(_ops._lib().dagnet_op_gru_layer_fwd(M, R, p(xs[0]), xs[0].stride(0), pieces[0], p(x1) if x1 is not None else None,
+                                                    x1.stride(0) if x1 is not None else 0, pieces[1] if x1 is not None else 0, p(h), R,
+                                                    p(Wih), K, p(bih), p(Whh), R, p(bhh), p(gi), p(gh), p(hn), p(gates),
+                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    x = torch.cat(xs, 1).double()
+    a, b = x @ Wih.double().t() + bih.double(), h.double() @ Whh.double().t() + bhh.double()
+    r, z = torch.sigmoid(a[:, :R] + b[:, :R]), torch.sigmoid(a[:, R:2 * R] + b[:, R:2 * R])
+    n = torch.tanh(a[:, 2 * R:] + r * b[:, 2 * R:])
+    tol = dict(rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(hn.double(), (1 - z) * n + z * h.double(), **tol)
+    torch.testing.assert_close(gates.double(), torch.cat([r, z, n], 1), **tol)
+    torch.testing.assert_close(gh[:, 2 * R:].double(), b[:, 2 * R:], **tol)

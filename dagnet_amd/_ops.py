@@ -22,7 +22,7 @@ ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
 OP_EXPORTS = (
     "dagnet_op_gemm", "dagnet_op_gemm_dact", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
-    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd",
+    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
     "dagnet_op_gat_attn_fwd", "dagnet_op_gat_attn_bwd", "dagnet_op_adj_matmul", "dagnet_op_disposition", "dagnet_op_sumsq",
@@ -51,7 +51,10 @@ def _lib():
         lib.dagnet_op_softmax_bwd.argtypes = [i64, i32, vp, i64, vp, i64, vp, i64, vp]
         lib.dagnet_op_gru_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_gru_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
-        lib.dagnet_op_gru_layer_fwd.argtypes = [i64, i32, vp, i64, i32, vp, i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp]
+        lib.dagnet_op_gru_layer_fwd.argtypes = [i64, i32, vp, i64, i32, vp, i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
+        lib.dagnet_op_gru_pack.argtypes = [i32, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]
+        lib.dagnet_op_gru_pack_floats.argtypes = [i32, i32, i32]
+        lib.dagnet_op_gru_pack_floats.restype = i64
         lib.dagnet_op_vae_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_vae_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp]
         lib.dagnet_op_nll_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp]
@@ -671,7 +674,7 @@ class GruLayerFn(torch.autograd.Function):
     products' input and weight gradients) - exactly as in the unfused form."""
 
     @staticmethod
-    def forward(ctx, gi, gh, h, Wih, bih, Whh, bhh, *xs):
+    def forward(ctx, gi, gh, h, Wih, bih, Whh, bhh, pack, *xs):
         M, R = h.shape
         ctx.slot = POOL.site()
         hn = POOL.at(ctx.slot, "hn", (M, R), h)
@@ -682,9 +685,9 @@ class GruLayerFn(torch.autograd.Function):
         if not (gi.is_contiguous() and gh.is_contiguous()):
             raise DagnetHipError("gate buffers must be contiguous")
         _check(_lib().dagnet_op_gru_layer_fwd(M, R, x0, ldx0, xs[0].shape[1], x1, ldx1, xs[1].shape[1] if len(xs) > 1 else 0, hp, ldh,
-                                              wi, ldwi, _p(bih), wh, ldwh, _p(bhh), _p(gi), _p(gh), _p(hn), _p(gates), _stream(h.device)))
+                                              wi, ldwi, _p(bih), wh, ldwh, _p(bhh), _p(gi), _p(gh), _p(hn), _p(gates), _p(pack), _stream(h.device)))
         ctx.save_for_backward(gates, gh, h)
-        ctx.n_extra = 4 + len(xs)
+        ctx.n_extra = 5 + len(xs)
         return hn
 
     @staticmethod
@@ -1033,7 +1036,26 @@ def gcn_train(gcn, x, adj, plan):
     return bn_train(gcn.bn2, x, True)
 
 
-def gru_step(rnn: torch.nn.GRU, xs, cols, h_layers):
+def gru_packs(rnn: torch.nn.GRU, widths):
+    """Per layer: the weights in the fused layer kernel's LDS order (csrc/gru_fused.hip), or None where the shape has no fused
+    kernel.  Valid until the weights change: training.forward_train builds them once per call, ahead of the time loop."""
+    lib, R, out = _lib(), rnn.hidden_size, []
+    for l in range(rnn.num_layers):
+        Wih, Whh = getattr(rnn, f"weight_ih_l{l}"), getattr(rnn, f"weight_hh_l{l}")
+        bih, bhh = getattr(rnn, f"bias_ih_l{l}", None), getattr(rnn, f"bias_hh_l{l}", None)
+        w = tuple(widths) if l == 0 else (R,)
+        n = lib.dagnet_op_gru_pack_floats(R, w[0], w[1] if len(w) > 1 else 0) if len(w) <= 2 and bih is not None and Wih.is_cuda else 0
+        if n <= 0:
+            out.append(None)
+            continue
+        pack = POOL.at(POOL.site(), "grupack", (n,), Wih)
+        (wi, ldwi), (wh, ldwh) = _m(Wih, "W_ih"), _m(Whh, "W_hh")
+        _check(lib.dagnet_op_gru_pack(R, w[0], w[1] if len(w) > 1 else 0, wi, ldwi, _p(bih), wh, ldwh, _p(bhh), _p(pack), _stream(Wih.device)))
+        out.append(pack)
+    return out
+
+
+def gru_step(rnn: torch.nn.GRU, xs, cols, h_layers, packs=None):
     """One seq_len = 1 call of nn.GRU; xs/cols: the pieces of the layer-0 input.  -> list of new per-layer states."""
     out = []
     for l in range(rnn.num_layers):
@@ -1049,7 +1071,7 @@ def gru_step(rnn: torch.nn.GRU, xs, cols, h_layers):
                 gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, 0, h_layers[l])
             finally:
                 _LAZY_LINEAR = False
-            hn = GruLayerFn.apply(gi, gh, h_layers[l], Wih, bih, Whh, bhh, *pieces)
+            hn = GruLayerFn.apply(gi, gh, h_layers[l], Wih, bih, Whh, bhh, packs[l] if packs else None, *pieces)
         else:
             gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, pcols, None, 0, 0, *pieces)
             gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, 0, h_layers[l])

@@ -1658,20 +1658,33 @@ extern "C" int dagnet_op_gru_fwd(int64_t M, int32_t R, const float *gi, const fl
 extern "C" hipError_t dn_gru_fused_fwd(int64_t M, int R, int npieces, const float *x0, int64_t ldx0, const float *x1, int64_t ldx1,
                                        const float *h, int64_t ldh, const float *Wih, int64_t ldwih, const float *bih, const float *Whh,
                                        int64_t ldwhh, const float *bhh, float *hn, int64_t ldhn, float *gates, int64_t ldg, float *gh,
-                                       int64_t ldgh, hipStream_t st);
+                                       int64_t ldgh, const float *pack, hipStream_t st);
+extern "C" int64_t dn_gru_pack_floats(int npieces);
+extern "C" hipError_t dn_gru_pack(int R, int npieces, const float *Wih, int64_t ldwih, const float *bih, const float *Whh, int64_t ldwhh,
+                                  const float *bhh, float *out, hipStream_t st);
+// -> floats of the packed image of a GRU layer that dagnet_op_gru_layer_fwd can take (0: this shape has no fused kernel)
+extern "C" int64_t dagnet_op_gru_pack_floats(int32_t R, int32_t K0, int32_t K1) {
+    return (R == 64 && K0 == 64 && (K1 == 0 || K1 == 64)) ? dn_gru_pack_floats(K1 ? 2 : 1) : 0;
+}
+extern "C" int dagnet_op_gru_pack(int32_t R, int32_t K0, int32_t K1, const float *Wih, int64_t ldwih, const float *bih, const float *Whh,
+                                  int64_t ldwhh, const float *bhh, float *out, void *stream) {
+    OP_NEED(dagnet_op_gru_pack_floats(R, K0, K1) > 0 && Wih && Whh && bih && bhh && out, "no fused GRU kernel for this shape");
+    HIP_TRY(dn_gru_pack(R, K1 ? 2 : 1, Wih, ldwih, bih, Whh, ldwhh, bhh, out, OP_ST));
+    return DAGNET_OK;
+}
 // One GRU layer step from its inputs.  The fused kernel (csrc/gru_fused.hip: rnn_dim 64, one or two 64-wide input pieces, >= 2048
 // rows) leaves gi untouched and writes only the n-gate columns of gh; any other shape runs as products + cell and fills both.
 extern "C" int dagnet_op_gru_layer_fwd(int64_t M, int32_t R, const float *x0, int64_t ldx0, int32_t K0, const float *x1, int64_t ldx1,
                                        int32_t K1, const float *h, int64_t ldh, const float *Wih, int64_t ldwih, const float *bih,
                                        const float *Whh, int64_t ldwhh, const float *bhh, float *gi, float *gh, float *hn, float *gates,
-                                       void *stream) {
+                                       const float *pack, void *stream) {
     OP_NEED(M >= 0 && R >= 1 && K0 >= 1 && K1 >= 0 && M < 0x7fffffffLL, "bad argument");
     if (M == 0) return DAGNET_OK;
     OP_NEED(x0 && (K1 == 0 || x1) && h && Wih && Whh && gi && gh && hn && gates, "null operand");
     static const bool no_fused = getenv("DAGNET_NO_GRU_FUSED") != nullptr;
     if (!no_fused && K0 == 64 && (K1 == 0 || K1 == 64)) {
         const hipError_t e = dn_gru_fused_fwd(M, R, K1 ? 2 : 1, x0, ldx0, x1, ldx1, h, ldh, Wih, ldwih, bih, Whh, ldwhh, bhh, hn, R, gates,
-                                              3 * R, gh, 3 * R, OP_ST);
+                                              3 * R, gh, 3 * R, pack, OP_ST);
         if (e == hipSuccess) return DAGNET_OK;
         if (e != hipErrorNotSupported) HIP_TRY(e);
     }

@@ -111,6 +111,7 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
             if kind == "dagnet" and isinstance(model.graph_goals, GAT):
                 st_goal = _ops.gat_stacks(model.graph_goals)
         h = [torch.zeros((N, R), dtype=torch.float32, device=dev) for _ in range(L)]
+        packs = _ops.gru_packs(model.rnn, (H, H))           # the GRU weights in the fused layer kernel's order, once per step
         k_rows, n_rows, c_rows = [], [], []
         br = _ops.BR
         for t in range(1, T):
@@ -151,7 +152,7 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
                     dec = fan(_mlp2(model.dec, [phi_z, hl], [0, H]))
                 mu_d, lv_d = linear(model.dec_mean, [dec], [0]), linear(model.dec_logvar, [dec], [0])
                 n_rows.append(NllFn.apply(mu_d, lv_d, x_t))
-            h = gru_step(model.rnn, [phi_x, phi_z], [0, H], h)
+            h = gru_step(model.rnn, [phi_x, phi_z], [0, H], h, packs)
             if kind != "vrnn":
                 h_g = _graph(graph, h[-1], adj[t], plan, st_hid)
                 h[-1] = fan(linear(blend, [h_g, h[-1]], [0, R]))

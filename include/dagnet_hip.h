@@ -238,10 +238,17 @@ int dagnet_op_gru_fwd(int64_t M, int32_t R, const float *gi, const float *gh, co
 /* Replaces: one layer of nn.GRU at seq_len = 1 from its inputs (models/dagnet/model.py:109-110,:186): gi = [x0 | x1] W_ih^T + b_ih,
  * gh = h W_hh^T + b_hh and the gate arithmetic in one call (x1 = NULL, K1 = 0: a single input piece).  gi, gh [M,3R], hn [M,R],
  * gates [M,3R] are contiguous.  rnn_dim 64 with 64-wide pieces and >= 2048 rows runs as ONE kernel (csrc/gru_fused.hip) that
- * leaves gi untouched and writes only columns 2R..3R of gh - all that dagnet_op_gru_bwd reads; other shapes fill both. */
+ * leaves gi untouched and writes only columns 2R..3R of gh - all that dagnet_op_gru_bwd reads; other shapes fill both.
+ * pack (nullable): the layer's weights in the kernel's LDS order, dagnet_op_gru_pack_floats(R, K0, K1) floats written by
+ * dagnet_op_gru_pack - valid until the weights change (a training step packs once for all its time steps); without it every
+ * workgroup gathers the image itself. */
 int dagnet_op_gru_layer_fwd(int64_t M, int32_t R, const float *x0, int64_t ldx0, int32_t K0, const float *x1, int64_t ldx1, int32_t K1,
                             const float *h, int64_t ldh, const float *Wih, int64_t ldwih, const float *bih, const float *Whh,
-                            int64_t ldwhh, const float *bhh, float *gi, float *gh, float *hn, float *gates, void *stream);
+                            int64_t ldwhh, const float *bhh, float *gi, float *gh, float *hn, float *gates, const float *pack,
+                            void *stream);
+int64_t dagnet_op_gru_pack_floats(int32_t R, int32_t K0, int32_t K1);
+int dagnet_op_gru_pack(int32_t R, int32_t K0, int32_t K1, const float *Wih, int64_t ldwih, const float *bih, const float *Whh,
+                       int64_t ldwhh, const float *bhh, float *out, void *stream);
 int dagnet_op_gru_bwd(int64_t M, int32_t R, const float *dhn, const float *gates, const float *gh, const float *h, float *dgi,
                       float *dgh, float *dh, void *stream);
 /* Replaces: _reparameterize + _kld (models/dagnet/model.py:118-128): z = eps exp(logvar_e / 2) + mean_e, kld_row[m] =

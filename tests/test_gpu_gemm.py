@@ -164,10 +164,18 @@ def test_gru_layer_matches_torch(M, pieces):
     hn, gates = torch.empty((M, R), device=DEV), torch.empty((M, 3 * R), device=DEV)
     p = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
     x1 = xs[1] if len(xs) > 1 else None
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    k1 = pieces[1] if x1 is not None else 0
+    n_pack = _ops._lib().dagnet_op_gru_pack_floats(R, pieces[0], k1)
+    assert (n_pack > 0) == all(k == 64 for k in pieces)
+    pack = None
+    if n_pack > 0 and M != 4100:                       # with the pre-packed weight image, and (M = 4100) without
+        pack = torch.empty(n_pack, device=DEV)
+        _ops._check(_ops._lib().dagnet_op_gru_pack(R, pieces[0], k1, p(Wih), K, p(bih), p(Whh), R, p(bhh), p(pack), st))
     _ops._check(_ops._lib().dagnet_op_gru_layer_fwd(M, R, p(xs[0]), xs[0].stride(0), pieces[0], p(x1) if x1 is not None else None,
-                                                    x1.stride(0) if x1 is not None else 0, pieces[1] if x1 is not None else 0, p(h), R,
+                                                    x1.stride(0) if x1 is not None else 0, k1, p(h), R,
                                                     p(Wih), K, p(bih), p(Whh), R, p(bhh), p(gi), p(gh), p(hn), p(gates),
-                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                                    p(pack) if pack is not None else None, st))
     x = torch.cat(xs, 1).double()
     a, b = x @ Wih.double().t() + bih.double(), h.double() @ Whh.double().t() + bhh.double()
     r, z = torch.sigmoid(a[:, :R] + b[:, :R]), torch.sigmoid(a[:, R:2 * R] + b[:, R:2 * R])

@@ -22,7 +22,7 @@ ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
 OP_EXPORTS = (
     "dagnet_op_gemm", "dagnet_op_gemm_dact", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
-    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
+    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
     "dagnet_op_gat_attn_fwd", "dagnet_op_gat_attn_bwd", "dagnet_op_adj_matmul", "dagnet_op_disposition", "dagnet_op_sumsq",
@@ -52,6 +52,8 @@ def _lib():
         lib.dagnet_op_gru_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_gru_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_gru_layer_fwd.argtypes = [i64, i32, vp, i64, i32, vp, i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
+        lib.dagnet_op_mlp2_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, i64, vp, i32, vp, i32, i32, C.c_float, vp, i64, vp, i32, i32, C.c_float,
+                                           vp, i64, vp, i64, vp]
         lib.dagnet_op_gru_pack.argtypes = [i32, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]
         lib.dagnet_op_gru_pack_floats.argtypes = [i32, i32, i32]
         lib.dagnet_op_gru_pack_floats.restype = i64
@@ -536,6 +538,48 @@ class LinearFn(torch.autograd.Function):
                 dxs[i] = POOL.at(ctx.slot, "dx%d" % i, (M, x.shape[1]), y)
                 gemm(dpre, W[:, c0:c0 + x.shape[1]], dxs[i], transb=True, K=N)
         return (dW, db, None, None, None, None, None, None, *dxs)
+
+
+class Mlp2Fn(torch.autograd.Function):
+    """Values of a two-layer block computed from its INPUTS by dagnet_op_mlp2_fwd (one kernel for the models' 64 / 64 blocks:
+    csrc/mlp_fused.hip) into the outputs y1, y2 of the two layers' LinearFn nodes, which were created lazily (allocated, not
+    computed) and keep the autograd graph - the backward pass is the unfused one.  -> an alias of y2."""
+
+    @staticmethod
+    def forward(ctx, y1, y2, W1, b1, act1, slope1, cols, gidx, gcol, W2, b2, act2, slope2, *xs):
+        M = y1.shape[0]
+        n = len(xs)
+        ptr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+        ldx = (C.c_int64 * n)(*[(x.stride(0) if M > 1 else x.shape[1]) for x in xs])
+        ks = (C.c_int32 * n)(*[x.shape[1] for x in xs])
+        cs = (C.c_int32 * n)(*[int(c) for c in cols])
+        for x in xs:
+            if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32:
+                raise DagnetHipError("input pieces must be fp32 matrices with unit column stride")
+        (w1, ldw1), (w2, ldw2), (p1, ld1), (p2, ld2) = _m(W1, "W1"), _m(W2, "W2"), _m(y1, "y1"), _m(y2, "y2")
+        _check(_lib().dagnet_op_mlp2_fwd(M, n, ptr, ldx, ks, cs, w1, ldw1, _p(b1), W1.shape[0], _p(gidx), int(gcol), act1, slope1, w2, ldw2,
+                                         _p(b2), W2.shape[0], act2, slope2, p1, ld1, p2, ld2, _stream(y1.device)))
+        ctx.n_extra = 11 + n
+        ctx.set_materialize_grads(False)
+        return y2.view_as(y2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return (None, dy, *([None] * ctx.n_extra))
+
+
+def mlp2(seq, xs, cols, act=ACT_LRELU, slope=0.01, gidx=None, gcol=0, gdim=0):
+    """seq = nn.Sequential(Linear, act, Linear, act) applied to [x_0 | ... | one-hot(gidx)]: the two LinearFn nodes are only recorded,
+    their values come from one dagnet_op_mlp2_fwd call."""
+    global _LAZY_LINEAR
+    l1, l2 = seq[0], seq[2]
+    _LAZY_LINEAR = True
+    try:
+        y1 = LinearFn.apply(l1.weight, l1.bias, act, slope, tuple(cols), gidx, gcol, gdim, *xs)
+        y2 = LinearFn.apply(l2.weight, l2.bias, act, slope, (0,), None, 0, 0, y1)
+    finally:
+        _LAZY_LINEAR = False
+    return Mlp2Fn.apply(y1, y2, l1.weight, l1.bias, act, slope, tuple(cols), gidx, gcol, l2.weight, l2.bias, act, slope, *xs)
 
 
 def linear(mod, xs: Sequence[torch.Tensor], cols: Sequence[int], act=ACT_NONE, slope=0.01, gidx=None, gcol=0, gdim=0):

@@ -1,0 +1,244 @@
+// Two dense layers of the training forward as ONE kernel: y1 = act1([x0 | x1 | x2 | one-hot(g)] W1^T + b1), y2 = act2(y1 W2^T + b2)
+// with 64 hidden and 64 output features (the phi_x / phi_z / enc / prior / dec blocks of models/dagnet/model.py:60-116: Linear,
+// LeakyReLU, Linear, LeakyReLU).  Layer by layer this is one launch per input piece (each re-reading and re-writing y1) plus one
+// for the second layer; here a wave owns 32-row tiles end to end (the skinny-GEMM scheme of gemm_skinny.hip): the pieces' rows
+// come straight from HBM as MFMA operands, and the first layer's accumulators (lane = row, register 4 a + i of tile nt <->
+// feature 32 nt + 8 a + 4 lh + i) ARE the second layer's operand quads (quad g = 4 nt + a, element i) - y1 goes from the
+// matrix cores back into them without leaving the registers.  Both outputs are written (the backward pass reads y1 too).
+//
+// Pieces: up to three; a piece is either a multiple of 8 columns wide with 16-byte rows (float4 operand loads) or - piece 0 only -
+// at most 4 columns of any layout (x_t and the disposition, 2 columns: scalar loads).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+namespace mlpf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_RELU = 3 };
+
+__device__ f32x4 mf_load4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
+__device__ float mf_load1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
+__device__ void mf_store4(f32x4 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+
+__device__ __forceinline__ i32x4 make_rsrc(const void *base, int64_t bytes) {
+    union { const void *p; int w[2]; } u;
+    u.p = base;
+    return i32x4{u.w[0], u.w[1], (int)(bytes > 0x7fffffffLL ? 0x7fffffffLL : bytes), 0x00020000};
+}
+
+__device__ __forceinline__ float act_apply(int act, float v, float slope) {
+    if (act == ACT_LRELU) return fmaxf(v, v * slope);
+    if (act == ACT_TANH) return tanhf(v);
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    return v;
+}
+
+struct Args {
+    const float *x0, *x1, *x2; int64_t ldx0, ldx1, ldx2; int K0, c0, c1, c2;      // pieces and their first columns in W1
+    const float *W1; int64_t ldw1; const float *b1;                                // [64, Ktot]
+    const int32_t *gidx; int gcol;                                                 // one-hot piece: y1 += W1[:, gcol + gidx[m]]
+    const float *W2; int64_t ldw2; const float *b2;                                // [64, 64]
+    float *y1; int64_t ldy1; float *y2; int64_t ldy2;
+    int M, act1, act2; float slope1, slope2;
+};
+
+// G0, G1, G2: k-groups of 8 per piece (0: piece absent; G0 = 1 with K0 <= 4 is the narrow form).
+constexpr int mlp_wpc(int KG) { return KG <= 4 ? 4 : (KG <= 8 ? 3 : 2); }      // workgroups per CU the registers allow
+
+template <int G0, int G1, int G2, bool NARROW, bool GATHER>
+__global__ __launch_bounds__(256, mlp_wpc(G0 + G1 + G2)) void mlp2_kernel(const Args p) {
+    constexpr int KG = G0 + G1 + G2;
+    extern __shared__ float lds[];           // w1 [2][KG][64][4] | w2 [2][8][64][4] | b1 [64] | b2 [64]
+    float *w1 = lds, *w2 = w1 + 2 * KG * 256, *bb = w2 + 2 * 8 * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    // ---- weight images: quad (tile nt, group g, lane l) = W[nt * 32 + (l & 31)][first column of g + 4 (l >> 5) .. + 3]
+    for (int e = tid; e < 2 * KG * 64; e += 256) {
+        const int l = e & 63, g = (e >> 6) % KG, nt = (e >> 6) / KG;
+        const int col = (g < G0 ? p.c0 + 8 * g : g < G0 + G1 ? p.c1 + 8 * (g - G0) : p.c2 + 8 * (g - G0 - G1)) + 4 * (l >> 5);
+        const float *src = p.W1 + (int64_t)(nt * 32 + (l & 31)) * p.ldw1 + col;
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (!NARROW || g > 0 || 4 * (l >> 5) + i < p.K0) ? src[i] : 0.f;
+        *reinterpret_cast<f32x4 *>(w1 + e * 4) = v;
+    }
+    for (int e = tid; e < 2 * 8 * 64; e += 256) {
+        const int l = e & 63, g = (e >> 6) & 7, nt = e >> 9;
+        const float *src = p.W2 + (int64_t)(nt * 32 + (l & 31)) * p.ldw2 + 8 * g + 4 * (l >> 5);
+        *reinterpret_cast<f32x4 *>(w2 + e * 4) = f32x4{src[0], src[1], src[2], src[3]};
+    }
+    if (tid < 64) {
+        bb[tid] = p.b1 ? p.b1[tid] : 0.f;
+        bb[64 + tid] = p.b2 ? p.b2[tid] : 0.f;
+    }
+    __syncthreads();
+
+    const int n_tiles = (p.M + 31) >> 5;
+    const int stride = (int)gridDim.x * 4;
+    int tile = (int)blockIdx.x * 4 + wave;
+    if (tile >= n_tiles) return;
+    const i32x4 r0 = make_rsrc(p.x0, (int64_t)p.M * p.ldx0 * 4);
+    const i32x4 r1 = make_rsrc(G1 ? p.x1 : p.x0, (int64_t)p.M * (G1 ? p.ldx1 : p.ldx0) * 4);
+    const i32x4 r2 = make_rsrc(G2 ? p.x2 : p.x0, (int64_t)p.M * (G2 ? p.ldx2 : p.ldx0) * 4);
+    const i32x4 ry1 = make_rsrc(p.y1, (int64_t)p.M * p.ldy1 * 4), ry2 = make_rsrc(p.y2, (int64_t)p.M * p.ldy2 * 4);
+    const i32x4 rw = make_rsrc(p.W1, 0x7fffffffLL);
+    const int ld04 = (int)p.ldx0 * 4, ld14 = (int)p.ldx1 * 4, ld24 = (int)p.ldx2 * 4, ldy14 = (int)p.ldy1 * 4, ldy24 = (int)p.ldy2 * 4;
+
+    f32x4 cur[KG], nxt[KG];
+    auto load_rows = [&](f32x4 (&d)[KG], int t) {
+        const int row = t * 32 + lr;             // rows past M lie beyond the buffers: the range check returns 0
+        if constexpr (NARROW) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float u = mf_load1(r0, row * ld04 + 4 * min(i, p.K0 - 1), 0, 0);
+                v[i] = (lh == 0 && i < p.K0) ? u : 0.f;
+            }
+            d[0] = v;
+        } else {
+#pragma unroll
+            for (int g = 0; g < G0; ++g) d[g] = mf_load4(r0, row * ld04 + 16 * lh + g * 32, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < G1; ++g) d[G0 + g] = mf_load4(r1, row * ld14 + 16 * lh + g * 32, 0, 0);
+#pragma unroll
+        for (int g = 0; g < G2; ++g) d[G0 + G1 + g] = mf_load4(r2, row * ld24 + 16 * lh + g * 32, 0, 0);
+    };
+    load_rows(cur, tile);
+    while (true) {
+        const int ntile = tile + stride;
+        const bool more = ntile < n_tiles;
+        if (more) load_rows(nxt, ntile);
+        const int row = tile * 32 + lr;
+        // one-hot piece: the 32 weights of this lane's (row, features) - loaded here, consumed after the MFMAs
+        float gpre[GATHER ? 2 : 1][16];
+        if (GATHER) {
+            const int gvoff = (p.gcol + p.gidx[min(row, p.M - 1)]) * 4, ldw4 = (int)p.ldw1 * 4;
+#pragma unroll
+            for (int nt = 0; nt < (GATHER ? 2 : 1); ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    gpre[nt][r] = mf_load1(rw, gvoff + (nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * ldw4, 0, 0);
+        }
+        f32x16 acc[2];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(w1 + ((nt * KG + g) * 64 + lane) * 4);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], cur[g][0], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], cur[g][1], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], cur[g][2], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], cur[g][3], acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);      // at most two weight quads in flight
+        }
+        // ---- first epilogue: y1 quads in operand order (quad 4 nt + a = features 32 nt + 8 a + 4 lh .. + 3)
+        f32x4 yq[8];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int f0 = nt * 32 + 8 * a + 4 * lh;
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(bb + f0);
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = acc[nt][4 * a + i] + b[i];
+                    if (GATHER) v[i] += gpre[nt][4 * a + i];
+                    v[i] = act_apply(p.act1, v[i], p.slope1);
+                }
+                yq[4 * nt + a] = v;
+                mf_store4(v, ry1, row * ldy14 + f0 * 4, 0, 0);
+            }
+        // ---- second layer
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(w2 + ((nt * 8 + g) * 64 + lane) * 4);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], yq[g][0], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], yq[g][1], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], yq[g][2], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], yq[g][3], acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int f0 = nt * 32 + 8 * a + 4 * lh;
+                const f32x4 b = *reinterpret_cast<const f32x4 *>(bb + 64 + f0);
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = act_apply(p.act2, acc[nt][4 * a + i] + b[i], p.slope2);
+                mf_store4(v, ry2, row * ldy24 + f0 * 4, 0, 0);
+            }
+        if (!more) break;
+        tile = ntile;
+#pragma unroll
+        for (int g = 0; g < KG; ++g) cur[g] = nxt[g];
+    }
+}
+
+template <int G0, int G1, int G2, bool NARROW>
+static hipError_t launch(const Args &a, hipStream_t st) {
+    constexpr int KG = G0 + G1 + G2;
+    const size_t lds = ((size_t)2 * KG * 256 + 2 * 8 * 256 + 128) * sizeof(float);
+    const int64_t tiles = ((int64_t)a.M + 31) / 32;
+    const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(mlp_wpc(KG), (160 * 1024) / (int64_t)lds));
+    const int64_t blocks = std::min<int64_t>((tiles + 3) / 4, 256 * per_cu);
+    if (a.gidx) hipLaunchKernelGGL((mlp2_kernel<G0, G1, G2, NARROW, true>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((mlp2_kernel<G0, G1, G2, NARROW, false>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace mlpf
+
+// -> hipErrorNotSupported for anything but: 64 hidden and output features, >= 2048 rows, pieces as described above in one of the
+// instantiated width combinations, 16-byte aligned y1 / y2 rows (the caller then runs the block layer by layer).
+extern "C" hipError_t dn_mlp2_fused(int64_t M, int npieces, const float *const *x, const int64_t *ldx, const int32_t *K, const int32_t *cols,
+                                    const float *W1, int64_t ldw1, const float *b1, int N1, const int32_t *gidx, int gcol, int act1,
+                                    float slope1, const float *W2, int64_t ldw2, const float *b2, int N2, int act2, float slope2, float *y1,
+                                    int64_t ldy1, float *y2, int64_t ldy2, hipStream_t st) {
+    if (N1 != 64 || N2 != 64 || M < 2048 || npieces < 1 || npieces > 3) return hipErrorNotSupported;
+    if ((ldy1 & 3) || (ldy2 & 3) || ldy1 < 64 || ldy2 < 64 || ((reinterpret_cast<uintptr_t>(y1) | reinterpret_cast<uintptr_t>(y2)) & 15))
+        return hipErrorNotSupported;
+    if (gcol < 0 || ldw1 > 4096 || M * std::max(ldy1, ldy2) * 4 >= 0x7fffffffLL) return hipErrorNotSupported;
+    int G[3] = {0, 0, 0};
+    const bool narrow = K[0] <= 4;
+    for (int i = 0; i < npieces; ++i) {
+        if (!x[i] || M * ldx[i] * 4 >= 0x7fffffffLL) return hipErrorNotSupported;
+        if (i == 0 && narrow) {
+            G[0] = 1;
+            continue;
+        }
+        if (K[i] % 8 || K[i] < 8 || K[i] > 64 || (ldx[i] & 3) || ldx[i] < K[i] || (reinterpret_cast<uintptr_t>(x[i]) & 15)) return hipErrorNotSupported;
+        G[i] = K[i] / 8;
+    }
+    mlpf::Args a{x[0], npieces > 1 ? x[1] : nullptr, npieces > 2 ? x[2] : nullptr, ldx[0], npieces > 1 ? ldx[1] : 0, npieces > 2 ? ldx[2] : 0,
+                 K[0], cols[0], npieces > 1 ? cols[1] : 0, npieces > 2 ? cols[2] : 0, W1, ldw1, b1, gidx, gcol, W2, ldw2, b2, y1, ldy1, y2, ldy2,
+                 (int)M, act1, act2, slope1, slope2};
+#define MLP_CASE(A, B, C, NARROW_)                                                                 \
+    if (G[0] == A && G[1] == B && G[2] == C && narrow == NARROW_) return mlpf::launch<A, B, C, NARROW_>(a, st);
+    MLP_CASE(1, 0, 0, true)      // phi_x: x_t
+    MLP_CASE(2, 0, 0, false)     // phi_z, z_dim 16
+    MLP_CASE(4, 0, 0, false)     // phi_z, z_dim 32
+    MLP_CASE(8, 0, 0, false)     // prior: h
+    MLP_CASE(8, 8, 0, false)     // enc: phi_x, h;  A-VRNN / VRNN dec: phi_z, h
+    MLP_CASE(1, 8, 8, true)      // DAG-Net dec: disposition, phi_z, h
+#undef MLP_CASE
+    return hipErrorNotSupported;
+}

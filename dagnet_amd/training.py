@@ -57,6 +57,8 @@ def attach_grad_arena(model, optimizer=None) -> torch.Tensor:
 
 
 def _mlp2(seq, xs, cols, gidx=None, gcol=0, gdim=0):
+    if len(xs) <= 3:
+        return _ops.mlp2(seq, xs, cols, act=ACT_LRELU, gidx=gidx, gcol=gcol, gdim=gdim)     # both layers in one kernel
     h = linear(seq[0], xs, cols, act=ACT_LRELU, gidx=gidx, gcol=gcol, gdim=gdim)
     return linear(seq[2], [h], [0], act=ACT_LRELU)
 

@@ -235,6 +235,15 @@ int dagnet_op_softmax_bwd(int64_t M, int32_t N, const float *Y, int64_t ldy, con
 /* Replaces: the gate arithmetic of nn.GRU (models/dagnet/model.py:116,185); gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh
  * [M,3R] come from dagnet_op_gemm.  gates [M,3R] keeps r, z, n for the backward. */
 int dagnet_op_gru_fwd(int64_t M, int32_t R, const float *gi, const float *gh, const float *h, float *hn, float *gates, void *stream);
+/* Replaces: the two-layer blocks phi_x / phi_z / enc / prior / dec (models/dagnet/model.py:60-116: Linear, LeakyReLU, Linear,
+ * LeakyReLU) applied to a concatenated input that is never materialised: y1 = act1([x_0 | x_1 | x_2 | one-hot(gidx)] W1^T + b1),
+ * y2 = act2(y1 W2^T + b2).  x, ldx, K, cols: HOST arrays of npieces (<= 3) device pointers, row strides, widths and first
+ * columns in W1; gidx (nullable): the one-hot piece at column gcol.  Both outputs are written (the backward pass reads y1).
+ * 64 / 64 features with >= 2048 rows run as ONE kernel (csrc/mlp_fused.hip); other shapes layer by layer. */
+int dagnet_op_mlp2_fwd(int64_t M, int32_t npieces, const float *const *x, const int64_t *ldx, const int32_t *K, const int32_t *cols,
+                       const float *W1, int64_t ldw1, const float *b1, int32_t N1, const int32_t *gidx, int32_t gcol, int32_t act1,
+                       float slope1, const float *W2, int64_t ldw2, const float *b2, int32_t N2, int32_t act2, float slope2, float *y1,
+                       int64_t ldy1, float *y2, int64_t ldy2, void *stream);
 /* Replaces: one layer of nn.GRU at seq_len = 1 from its inputs (models/dagnet/model.py:109-110,:186): gi = [x0 | x1] W_ih^T + b_ih,
  * gh = h W_hh^T + b_hh and the gate arithmetic in one call (x1 = NULL, K1 = 0: a single input piece).  gi, gh [M,3R], hn [M,R],
  * gates [M,3R] are contiguous.  rnn_dim 64 with 64-wide pieces and >= 2048 rows runs as ONE kernel (csrc/gru_fused.hip) that

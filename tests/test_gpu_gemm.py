@@ -184,3 +184,41 @@ def test_gru_layer_matches_torch(M, pieces):
     torch.testing.assert_close(hn.double(), (1 - z) * n + z * h.double(), **tol)
     torch.testing.assert_close(gates.double(), torch.cat([r, z, n], 1), **tol)
     torch.testing.assert_close(gh[:, 2 * R:].double(), b[:, 2 * R:], **tol)
+
+
+@pytest.mark.parametrize("M,pieces,gather", [(4100, (2,), False), (3000, (32,), False), (2500, (16,), False), (5000, (64,), True), (4096, (64, 64), True),
+                                             (2049, (64, 64), False), (3100, (2, 64, 64), True), (100, (64, 64), True), (3000, (16, 64), True),
+                                             (40960, (2, 64, 64), True)])
+def test_mlp2_matches_torch(M, pieces, gather):
+    """dagnet_op_mlp2_fwd (one kernel for the models' block shapes, layer by layer otherwise - small M, the (16, 64) combination)
+    against two nn.Linear + LeakyReLU in fp64 on the concatenated input, both outputs."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(M + 7 * sum(pieces) + int(gather))
+    G = 90 if gather else 0
+    cols, c = [], 0
+    for i, k in enumerate(pieces):              # the one-hot block sits after the first piece (as in enc / prior / dec)
+        cols.append(c)
+        c += k + (G if i == 0 else 0)
+    gcol, Ktot = pieces[0], c
+    xs = [torch.randn((M, k), generator=g).to(DEV) for k in pieces]
+    W1, b1 = (torch.randn((64, Ktot), generator=g) / Ktot ** 0.5).to(DEV), torch.randn(64, generator=g).to(DEV)
+    W2, b2 = (torch.randn((64, 64), generator=g) / 8).to(DEV), torch.randn(64, generator=g).to(DEV)
+    gidx = torch.randint(0, G, (M,), generator=g).to(torch.int32).to(DEV) if gather else None
+    y1, y2 = torch.full((M, 64), float("nan"), device=DEV), torch.full((M, 64), float("nan"), device=DEV)
+    n = len(xs)
+    ptr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    ldx = (C.c_int64 * n)(*[x.stride(0) for x in xs])
+    ks, cs = (C.c_int32 * n)(*pieces), (C.c_int32 * n)(*cols)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    _ops._check(_ops._lib().dagnet_op_mlp2_fwd(M, n, ptr, ldx, ks, cs, p(W1), Ktot, p(b1), 64, p(gidx), gcol, _ops.ACT_LRELU, 0.01, p(W2), 64,
+                                               p(b2), 64, _ops.ACT_LRELU, 0.01, p(y1), 64, p(y2), 64,
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    full = torch.zeros((M, Ktot), dtype=torch.float64, device=DEV)
+    for x, c0 in zip(xs, cols):
+        full[:, c0:c0 + x.shape[1]] = x.double()
+    if gather:
+        full[torch.arange(M, device=DEV), gcol + gidx.long()] = 1.0
+    r1 = torch.nn.functional.leaky_relu(full @ W1.double().t() + b1.double(), 0.01)
+    r2 = torch.nn.functional.leaky_relu(r1 @ W2.double().t() + b2.double(), 0.01)
+    torch.testing.assert_close(y1.double(), r1, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(y2.double(), r2, rtol=2e-5, atol=2e-5)

@@ -22,7 +22,7 @@ ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
 OP_EXPORTS = (
     "dagnet_op_gemm", "dagnet_op_gemm_dact", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
-    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
+    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_mlp_chain_fwd", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
     "dagnet_op_gat_attn_fwd", "dagnet_op_gat_attn_bwd", "dagnet_op_adj_matmul", "dagnet_op_disposition", "dagnet_op_sumsq",
@@ -54,6 +54,8 @@ def _lib():
         lib.dagnet_op_gru_layer_fwd.argtypes = [i64, i32, vp, i64, i32, vp, i64, i32, vp, i64, vp, i64, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_mlp2_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, i64, vp, i32, vp, i32, i32, C.c_float, vp, i64, vp, i32, i32, C.c_float,
                                            vp, i64, vp, i64, vp]
+        lib.dagnet_op_mlp_chain_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, i64, vp, i32, vp, i32, i32, C.c_float, vp, i64, vp, i32, i32, C.c_float,
+                                                vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i32, vp, i64, vp, i64, vp]
         lib.dagnet_op_gru_pack.argtypes = [i32, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]
         lib.dagnet_op_gru_pack_floats.argtypes = [i32, i32, i32]
         lib.dagnet_op_gru_pack_floats.restype = i64
@@ -540,46 +542,88 @@ class LinearFn(torch.autograd.Function):
         return (dW, db, None, None, None, None, None, None, *dxs)
 
 
-class Mlp2Fn(torch.autograd.Function):
-    """Values of a two-layer block computed from its INPUTS by dagnet_op_mlp2_fwd (one kernel for the models' 64 / 64 blocks:
-    csrc/mlp_fused.hip) into the outputs y1, y2 of the two layers' LinearFn nodes, which were created lazily (allocated, not
-    computed) and keep the autograd graph - the backward pass is the unfused one.  -> an alias of y2."""
+class MlpChainFn(torch.autograd.Function):
+    """Values of a block of dense layers computed from the block's INPUTS by dagnet_op_mlp_chain_fwd (one kernel for the models'
+    64-wide blocks: csrc/mlp_fused.hip) into the outputs of the layers' LinearFn nodes, which were created lazily (allocated,
+    not computed) and keep the autograd graph - the backward pass is the unfused one.  Layers: first (y1), optional second (y2),
+    optional pair of heads on y2 (mu, lv).  -> aliases of (the last of y1 / y2[, mu, lv])."""
 
     @staticmethod
-    def forward(ctx, y1, y2, W1, b1, act1, slope1, cols, gidx, gcol, W2, b2, act2, slope2, *xs):
+    def forward(ctx, y1, y2, mu, lv, l1, l2, heads, act, slope, cols, gidx, gcol, *xs):
         M = y1.shape[0]
         n = len(xs)
+        for x in xs:
+            if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32:
+                raise DagnetHipError("input pieces must be fp32 matrices with unit column stride")
         ptr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
         ldx = (C.c_int64 * n)(*[(x.stride(0) if M > 1 else x.shape[1]) for x in xs])
         ks = (C.c_int32 * n)(*[x.shape[1] for x in xs])
         cs = (C.c_int32 * n)(*[int(c) for c in cols])
-        for x in xs:
-            if x.dim() != 2 or x.stride(1) != 1 or x.dtype != torch.float32:
-                raise DagnetHipError("input pieces must be fp32 matrices with unit column stride")
-        (w1, ldw1), (w2, ldw2), (p1, ld1), (p2, ld2) = _m(W1, "W1"), _m(W2, "W2"), _m(y1, "y1"), _m(y2, "y2")
-        _check(_lib().dagnet_op_mlp2_fwd(M, n, ptr, ldx, ks, cs, w1, ldw1, _p(b1), W1.shape[0], _p(gidx), int(gcol), act1, slope1, w2, ldw2,
-                                         _p(b2), W2.shape[0], act2, slope2, p1, ld1, p2, ld2, _stream(y1.device)))
-        ctx.n_extra = 11 + n
+        (W1, b1) = l1
+        (w1, ldw1), (p1, ld1) = _m(W1, "W1"), _m(y1, "y1")
+        (W2, b2) = l2 if l2 is not None else (None, None)
+        (w2, ldw2), (p2, ld2) = (_m(W2, "W2"), _m(y2, "y2")) if l2 is not None else ((None, 0), (None, 0))
+        if heads is not None:
+            (Wm, bm), (Wl, bl) = heads
+            (wm, ldwm), (wl, ldwl), (pm, ldm), (pl, ldl) = _m(Wm, "W_mean"), _m(Wl, "W_logvar"), _m(mu, "mu"), _m(lv, "lv")
+            Z = Wm.shape[0]
+        else:
+            wm = wl = pm = pl = bm = bl = None
+            ldwm = ldwl = ldm = ldl = Z = 0
+        _check(_lib().dagnet_op_mlp_chain_fwd(M, n, ptr, ldx, ks, cs, w1, ldw1, _p(b1), W1.shape[0], _p(gidx), int(gcol), act[0], slope, w2, ldw2,
+                                              _p(b2), W2.shape[0] if W2 is not None else 0, act[1], slope, p1, ld1, p2, ld2, wm, ldwm, _p(bm),
+                                              wl, ldwl, _p(bl), Z, pm, ldm, pl, ldl, _stream(y1.device)))
+        ctx.n_in = 12 + n
+        ctx.has = (y2 is not None, heads is not None)
         ctx.set_materialize_grads(False)
-        return y2.view_as(y2)
+        last = y2 if y2 is not None else y1
+        if heads is not None:
+            return last.view_as(last), mu.view_as(mu), lv.view_as(lv)
+        return last.view_as(last)
 
     @staticmethod
-    def backward(ctx, dy):
-        return (None, dy, *([None] * ctx.n_extra))
+    def backward(ctx, *g):
+        two, heads = ctx.has
+        out = [None] * ctx.n_in
+        out[1 if two else 0] = g[0]
+        if heads:
+            out[2], out[3] = g[1], g[2]
+        return tuple(out)
 
 
-def mlp2(seq, xs, cols, act=ACT_LRELU, slope=0.01, gidx=None, gcol=0, gdim=0):
-    """seq = nn.Sequential(Linear, act, Linear, act) applied to [x_0 | ... | one-hot(gidx)]: the two LinearFn nodes are only recorded,
-    their values come from one dagnet_op_mlp2_fwd call."""
+def mlp2(seq, xs, cols, act=ACT_LRELU, slope=0.01, gidx=None, gcol=0, gdim=0, heads=None):
+    """seq = nn.Sequential(Linear, act, Linear, act) applied to [x_0 | ... | one-hot(gidx)]: the LinearFn nodes are only recorded,
+    their values come from one dagnet_op_mlp_chain_fwd call.  heads = (mean, logvar) nn.Linear modules that read the block's output:
+    -> (fan-out alias of the output, mean, logvar), all three from the same call; else -> the output."""
     global _LAZY_LINEAR
     l1, l2 = seq[0], seq[2]
     _LAZY_LINEAR = True
     try:
         y1 = LinearFn.apply(l1.weight, l1.bias, act, slope, tuple(cols), gidx, gcol, gdim, *xs)
         y2 = LinearFn.apply(l2.weight, l2.bias, act, slope, (0,), None, 0, 0, y1)
+        if heads is not None:
+            out = fanout(y2)
+            mu = LinearFn.apply(heads[0].weight, heads[0].bias, ACT_NONE, 0.0, (0,), None, 0, 0, out)
+            lv = LinearFn.apply(heads[1].weight, heads[1].bias, ACT_NONE, 0.0, (0,), None, 0, 0, out)
     finally:
         _LAZY_LINEAR = False
-    return Mlp2Fn.apply(y1, y2, l1.weight, l1.bias, act, slope, tuple(cols), gidx, gcol, l2.weight, l2.bias, act, slope, *xs)
+    w = ((l1.weight, l1.bias), (l2.weight, l2.bias))
+    if heads is None:
+        return MlpChainFn.apply(y1, y2, None, None, w[0], w[1], None, (act, act), slope, tuple(cols), gidx, gcol, *xs)
+    hw = ((heads[0].weight, heads[0].bias), (heads[1].weight, heads[1].bias))
+    _, mu_a, lv_a = MlpChainFn.apply(y1, y2, mu, lv, w[0], w[1], hw, (act, act), slope, tuple(cols), gidx, gcol, *xs)
+    return out, mu_a, lv_a
+
+
+def linear_pieces(mod, xs, cols, act=ACT_NONE, slope=0.01):
+    """nn.Linear over [x_0 | x_1 | ...] as ONE kernel (instead of one accumulating product per piece)."""
+    global _LAZY_LINEAR
+    _LAZY_LINEAR = True
+    try:
+        y1 = LinearFn.apply(mod.weight, mod.bias, act, slope, tuple(cols), None, 0, 0, *xs)
+    finally:
+        _LAZY_LINEAR = False
+    return MlpChainFn.apply(y1, None, None, None, (mod.weight, mod.bias), None, None, (act, ACT_NONE), slope, tuple(cols), None, 0, *xs)
 
 
 def linear(mod, xs: Sequence[torch.Tensor], cols: Sequence[int], act=ACT_NONE, slope=0.01, gidx=None, gcol=0, gdim=0):

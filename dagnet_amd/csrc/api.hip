@@ -1696,24 +1696,39 @@ extern "C" int dagnet_op_gru_layer_fwd(int64_t M, int32_t R, const float *x0, in
     HIP_TRY(dn_t_gru_fwd(M, R, gi, gh, h, hn, gates, OP_ST));
     return DAGNET_OK;
 }
-extern "C" hipError_t dn_mlp2_fused(int64_t M, int npieces, const float *const *x, const int64_t *ldx, const int32_t *K, const int32_t *cols,
-                                    const float *W1, int64_t ldw1, const float *b1, int N1, const int32_t *gidx, int gcol, int act1,
-                                    float slope1, const float *W2, int64_t ldw2, const float *b2, int N2, int act2, float slope2, float *y1,
-                                    int64_t ldy1, float *y2, int64_t ldy2, hipStream_t st);
 // y1 = act1([x_0 | x_1 | x_2 | one-hot(gidx)] W1^T + b1) [M,N1], y2 = act2(y1 W2^T + b2) [M,N2]; piece s sits at columns cols[s] of W1,
 // the one-hot block at gcol.  One kernel for the 64 / 64 blocks of the models (csrc/mlp_fused.hip), layer by layer otherwise.
 extern "C" int dagnet_op_mlp2_fwd(int64_t M, int32_t npieces, const float *const *x, const int64_t *ldx, const int32_t *K,
                                   const int32_t *cols, const float *W1, int64_t ldw1, const float *b1, int32_t N1, const int32_t *gidx,
                                   int32_t gcol, int32_t act1, float slope1, const float *W2, int64_t ldw2, const float *b2, int32_t N2,
                                   int32_t act2, float slope2, float *y1, int64_t ldy1, float *y2, int64_t ldy2, void *stream) {
-    OP_NEED(M >= 0 && M < 0x7fffffffLL && npieces >= 1 && npieces <= 3 && N1 >= 1 && N2 >= 1 && x && ldx && K && cols, "bad argument");
+    OP_NEED(W2 && y2 && N2 >= 1, "null operand");
+    return dagnet_op_mlp_chain_fwd(M, npieces, x, ldx, K, cols, W1, ldw1, b1, N1, gidx, gcol, act1, slope1, W2, ldw2, b2, N2, act2, slope2, y1,
+                                   ldy1, y2, ldy2, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, stream);
+}
+extern "C" hipError_t dn_mlp_chain_fused(int64_t M, int npieces, const float *const *x, const int64_t *ldx, const int32_t *K,
+                                         const int32_t *cols, const float *W1, int64_t ldw1, const float *b1, int N1, const int32_t *gidx,
+                                         int gcol, int act1, float slope1, const float *W2, int64_t ldw2, const float *b2, int N2, int act2,
+                                         float slope2, float *y1, int64_t ldy1, float *y2, int64_t ldy2, const float *Wm, int64_t ldwm,
+                                         const float *bm, const float *Wl, int64_t ldwl, const float *bl, int Z, float *mu, int64_t ldmu,
+                                         float *lv, int64_t ldlv, hipStream_t st);
+// dagnet_op_mlp2_fwd with optional layers: W2 == NULL stops after y1; Wm / Wl != NULL append the two heads mu = y2 Wm^T + bm and
+// lv = y2 Wl^T + bl ([M,Z] each, no activation).
+extern "C" int dagnet_op_mlp_chain_fwd(int64_t M, int32_t npieces, const float *const *x, const int64_t *ldx, const int32_t *K,
+                                       const int32_t *cols, const float *W1, int64_t ldw1, const float *b1, int32_t N1, const int32_t *gidx,
+                                       int32_t gcol, int32_t act1, float slope1, const float *W2, int64_t ldw2, const float *b2, int32_t N2,
+                                       int32_t act2, float slope2, float *y1, int64_t ldy1, float *y2, int64_t ldy2, const float *Wm,
+                                       int64_t ldwm, const float *bm, const float *Wl, int64_t ldwl, const float *bl, int32_t Z, float *mu,
+                                       int64_t ldmu, float *lv, int64_t ldlv, void *stream) {
+    OP_NEED(M >= 0 && M < 0x7fffffffLL && npieces >= 1 && npieces <= 3 && N1 >= 1 && x && ldx && K && cols, "bad argument");
     if (M == 0) return DAGNET_OK;
-    OP_NEED(W1 && W2 && y1 && y2, "null operand");
+    OP_NEED(W1 && y1 && (!W2 || (y2 && N2 >= 1)), "null operand");
+    OP_NEED((!Wm && !Wl) || (W2 && Wm && Wl && mu && lv && Z >= 1), "heads need both weight matrices, both outputs and the second layer");
     for (int i = 0; i < npieces; ++i) OP_NEED(x[i] && K[i] >= 1, "null or empty input piece");
     static const bool no_fused = getenv("DAGNET_NO_MLP_FUSED") != nullptr;
     if (!no_fused) {
-        const hipError_t e = dn_mlp2_fused(M, npieces, x, ldx, K, cols, W1, ldw1, b1, N1, gidx, gcol, act1, slope1, W2, ldw2, b2, N2, act2,
-                                           slope2, y1, ldy1, y2, ldy2, OP_ST);
+        const hipError_t e = dn_mlp_chain_fused(M, npieces, x, ldx, K, cols, W1, ldw1, b1, N1, gidx, gcol, act1, slope1, W2, ldw2, b2, N2, act2,
+                                                slope2, y1, ldy1, y2, ldy2, Wm, ldwm, bm, Wl, ldwl, bl, Z, mu, ldmu, lv, ldlv, OP_ST);
         if (e == hipSuccess) return DAGNET_OK;
         if (e != hipErrorNotSupported) HIP_TRY(e);
     }
@@ -1722,7 +1737,12 @@ extern "C" int dagnet_op_mlp2_fwd(int64_t M, int32_t npieces, const float *const
         HIP_TRY(dn_gemm(x[i], ldx[i], W1 + cols[i], ldw1, 0, fin ? b1 : nullptr, y1, ldy1, (int)M, N1, K[i], fin ? act1 : 0, slope1, i > 0,
                         fin && gidx ? W1 + gcol : nullptr, fin ? gidx : nullptr, 1, ldw1, OP_ST));
     }
+    if (!W2) return DAGNET_OK;
     HIP_TRY(dn_gemm(y1, ldy1, W2, ldw2, 0, b2, y2, ldy2, (int)M, N2, N1, act2, slope2, 0, nullptr, nullptr, 0, 0, OP_ST));
+    if (Wm) {
+        HIP_TRY(dn_gemm(y2, ldy2, Wm, ldwm, 0, bm, mu, ldmu, (int)M, Z, N2, 0, 0.f, 0, nullptr, nullptr, 0, 0, OP_ST));
+        HIP_TRY(dn_gemm(y2, ldy2, Wl, ldwl, 0, bl, lv, ldlv, (int)M, Z, N2, 0, 0.f, 0, nullptr, nullptr, 0, 0, OP_ST));
+    }
     return DAGNET_OK;
 }
 extern "C" int dagnet_op_gru_bwd(int64_t M, int32_t R, const float *dhn, const float *gates, const float *gh, const float *h, float *dgi,

@@ -6,6 +6,9 @@
 // feature 32 nt + 8 a + 4 lh + i) ARE the second layer's operand quads (quad g = 4 nt + a, element i) - y1 goes from the
 // matrix cores back into them without leaving the registers.  Both outputs are written (the backward pass reads y1 too).
 //
+// MODE 1 stops after the first layer (lg_hiddens: two pieces, no activation); MODE 2 appends the two heads that read y2 (enc_mean /
+// enc_logvar, prior_*, dec_*: 64 -> Z each, no activation) as a third product on the y2 accumulators, written to mu and lv.
+//
 // Pieces: up to three; a piece is either a multiple of 8 columns wide with 16-byte rows (float4 operand loads) or - piece 0 only -
 // at most 4 columns of any layout (x_t and the disposition, 2 columns: scalar loads).
 #include <hip/hip_runtime.h>
@@ -23,6 +26,7 @@ enum { ACT_NONE = 0, ACT_LRELU = 1, ACT_TANH = 2, ACT_RELU = 3 };
 __device__ f32x4 mf_load4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ float mf_load1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void mf_store4(f32x4 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+__device__ void mf_store1(float data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
 
 __device__ __forceinline__ i32x4 make_rsrc(const void *base, int64_t bytes) {
     union { const void *p; int w[2]; } u;
@@ -44,16 +48,19 @@ struct Args {
     const float *W2; int64_t ldw2; const float *b2;                                // [64, 64]
     float *y1; int64_t ldy1; float *y2; int64_t ldy2;
     int M, act1, act2; float slope1, slope2;
+    // heads (MODE 2): mu = y2 Wm^T + bm, lv = y2 Wl^T + bl, Z columns each
+    const float *Wm, *Wl; int64_t ldwm, ldwl; const float *bm, *bl; int Z; float *mu, *lv; int64_t ldmu, ldlv;
 };
 
 // G0, G1, G2: k-groups of 8 per piece (0: piece absent; G0 = 1 with K0 <= 4 is the narrow form).
 constexpr int mlp_wpc(int KG) { return KG <= 4 ? 4 : (KG <= 8 ? 3 : 2); }      // workgroups per CU the registers allow
 
-template <int G0, int G1, int G2, bool NARROW, bool GATHER>
+// MODE: 0 = two layers, 1 = the first layer only, 2 = two layers + heads (NT3 = 32-wide tiles of the stacked heads, 2 Z <= 32 NT3)
+template <int G0, int G1, int G2, bool NARROW, bool GATHER, int MODE, int NT3>
 __global__ __launch_bounds__(256, mlp_wpc(G0 + G1 + G2)) void mlp2_kernel(const Args p) {
     constexpr int KG = G0 + G1 + G2;
-    extern __shared__ float lds[];           // w1 [2][KG][64][4] | w2 [2][8][64][4] | b1 [64] | b2 [64]
-    float *w1 = lds, *w2 = w1 + 2 * KG * 256, *bb = w2 + 2 * 8 * 256;
+    extern __shared__ float lds[];           // w1 [2][KG][64][4] | w2 [2][8][64][4] | w3 [NT3][8][64][4] | b1, b2, b3 [64] each
+    float *w1 = lds, *w2 = w1 + 2 * KG * 256, *w3 = w2 + (MODE != 1 ? 2 * 8 * 256 : 0), *bb = w3 + (MODE == 2 ? NT3 * 8 * 256 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     // ---- weight images: quad (tile nt, group g, lane l) = W[nt * 32 + (l & 31)][first column of g + 4 (l >> 5) .. + 3]
     for (int e = tid; e < 2 * KG * 64; e += 256) {
@@ -65,14 +72,30 @@ __global__ __launch_bounds__(256, mlp_wpc(G0 + G1 + G2)) void mlp2_kernel(const 
         for (int i = 0; i < 4; ++i) v[i] = (!NARROW || g > 0 || 4 * (l >> 5) + i < p.K0) ? src[i] : 0.f;
         *reinterpret_cast<f32x4 *>(w1 + e * 4) = v;
     }
-    for (int e = tid; e < 2 * 8 * 64; e += 256) {
-        const int l = e & 63, g = (e >> 6) & 7, nt = e >> 9;
-        const float *src = p.W2 + (int64_t)(nt * 32 + (l & 31)) * p.ldw2 + 8 * g + 4 * (l >> 5);
-        *reinterpret_cast<f32x4 *>(w2 + e * 4) = f32x4{src[0], src[1], src[2], src[3]};
+    if constexpr (MODE != 1) {
+        for (int e = tid; e < 2 * 8 * 64; e += 256) {
+            const int l = e & 63, g = (e >> 6) & 7, nt = e >> 9;
+            const float *src = p.W2 + (int64_t)(nt * 32 + (l & 31)) * p.ldw2 + 8 * g + 4 * (l >> 5);
+            *reinterpret_cast<f32x4 *>(w2 + e * 4) = f32x4{src[0], src[1], src[2], src[3]};
+        }
+    }
+    if constexpr (MODE == 2) {               // the two heads stacked along the output features: [mean | logvar | zeros]
+        for (int e = tid; e < NT3 * 8 * 64; e += 256) {
+            const int l = e & 63, g = (e >> 6) & 7, nt = e >> 9, n = nt * 32 + (l & 31);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < 2 * p.Z) {
+                const float *src = (n < p.Z ? p.Wm + (int64_t)n * p.ldwm : p.Wl + (int64_t)(n - p.Z) * p.ldwl) + 8 * g + 4 * (l >> 5);
+                v = f32x4{src[0], src[1], src[2], src[3]};
+            }
+            *reinterpret_cast<f32x4 *>(w3 + e * 4) = v;
+        }
     }
     if (tid < 64) {
         bb[tid] = p.b1 ? p.b1[tid] : 0.f;
-        bb[64 + tid] = p.b2 ? p.b2[tid] : 0.f;
+        bb[64 + tid] = (MODE != 1 && p.b2) ? p.b2[tid] : 0.f;
+        float b3 = 0.f;
+        if (MODE == 2 && tid < 2 * p.Z) b3 = tid < p.Z ? (p.bm ? p.bm[tid] : 0.f) : (p.bl ? p.bl[tid - p.Z] : 0.f);
+        bb[128 + tid] = b3;
     }
     __syncthreads();
 
@@ -83,7 +106,8 @@ __global__ __launch_bounds__(256, mlp_wpc(G0 + G1 + G2)) void mlp2_kernel(const 
     const i32x4 r0 = make_rsrc(p.x0, (int64_t)p.M * p.ldx0 * 4);
     const i32x4 r1 = make_rsrc(G1 ? p.x1 : p.x0, (int64_t)p.M * (G1 ? p.ldx1 : p.ldx0) * 4);
     const i32x4 r2 = make_rsrc(G2 ? p.x2 : p.x0, (int64_t)p.M * (G2 ? p.ldx2 : p.ldx0) * 4);
-    const i32x4 ry1 = make_rsrc(p.y1, (int64_t)p.M * p.ldy1 * 4), ry2 = make_rsrc(p.y2, (int64_t)p.M * p.ldy2 * 4);
+    const i32x4 ry1 = make_rsrc(p.y1, (int64_t)p.M * p.ldy1 * 4), ry2 = make_rsrc(MODE != 1 ? p.y2 : p.y1, (int64_t)p.M * (MODE != 1 ? p.ldy2 : p.ldy1) * 4);
+    const i32x4 rmu = make_rsrc(MODE == 2 ? p.mu : p.y1, MODE == 2 ? (int64_t)p.M * p.ldmu * 4 : 0), rlv = make_rsrc(MODE == 2 ? p.lv : p.y1, MODE == 2 ? (int64_t)p.M * p.ldlv * 4 : 0);
     const i32x4 rw = make_rsrc(p.W1, 0x7fffffffLL);
     const int ld04 = (int)p.ldx0 * 4, ld14 = (int)p.ldx1 * 4, ld24 = (int)p.ldx2 * 4, ldy14 = (int)p.ldy1 * 4, ldy24 = (int)p.ldy2 * 4;
 
@@ -158,6 +182,7 @@ __global__ __launch_bounds__(256, mlp_wpc(G0 + G1 + G2)) void mlp2_kernel(const 
                 yq[4 * nt + a] = v;
                 mf_store4(v, ry1, row * ldy14 + f0 * 4, 0, 0);
             }
+        if constexpr (MODE != 1) {
         // ---- second layer
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
@@ -185,7 +210,51 @@ __global__ __launch_bounds__(256, mlp_wpc(G0 + G1 + G2)) void mlp2_kernel(const 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) v[i] = act_apply(p.act2, acc[nt][4 * a + i] + b[i], p.slope2);
                 mf_store4(v, ry2, row * ldy24 + f0 * 4, 0, 0);
+                yq[4 * nt + a] = v;
             }
+        }
+        if constexpr (MODE == 2) {
+            // ---- heads: one product over the stacked [mean | logvar] rows; the quads of a feature range go to mu or to lv
+            f32x16 ah[NT3];
+#pragma unroll
+            for (int nt = 0; nt < NT3; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ah[nt][r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+#pragma unroll
+                for (int nt = 0; nt < NT3; ++nt) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(w3 + ((nt * 8 + g) * 64 + lane) * 4);
+                    ah[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], yq[g][0], ah[nt], 0, 0, 0);
+                    ah[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], yq[g][1], ah[nt], 0, 0, 0);
+                    ah[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], yq[g][2], ah[nt], 0, 0, 0);
+                    ah[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], yq[g][3], ah[nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int ldmu4 = (int)p.ldmu * 4, ldlv4 = (int)p.ldlv * 4;
+#pragma unroll
+            for (int nt = 0; nt < NT3; ++nt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int f0 = nt * 32 + 8 * a + 4 * lh;
+                    const f32x4 b = *reinterpret_cast<const f32x4 *>(bb + 128 + f0);
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = ah[nt][4 * a + i] + b[i];
+                    if ((p.Z & 3) == 0) {
+                        if (f0 < p.Z) mf_store4(v, rmu, row * ldmu4 + f0 * 4, 0, 0);
+                        else if (f0 < 2 * p.Z) mf_store4(v, rlv, row * ldlv4 + (f0 - p.Z) * 4, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int f = f0 + i;
+                            if (f < p.Z) mf_store1(v[i], rmu, row * ldmu4 + f * 4, 0, 0);
+                            else if (f < 2 * p.Z) mf_store1(v[i], rlv, row * ldlv4 + (f - p.Z) * 4, 0, 0);
+                        }
+                    }
+                }
+        }
         if (!more) break;
         tile = ntile;
 #pragma unroll
@@ -193,30 +262,42 @@ __global__ __launch_bounds__(256, mlp_wpc(G0 + G1 + G2)) void mlp2_kernel(const 
     }
 }
 
-template <int G0, int G1, int G2, bool NARROW>
+template <int G0, int G1, int G2, bool NARROW, int MODE, int NT3>
 static hipError_t launch(const Args &a, hipStream_t st) {
     constexpr int KG = G0 + G1 + G2;
-    const size_t lds = ((size_t)2 * KG * 256 + 2 * 8 * 256 + 128) * sizeof(float);
+    const size_t lds = ((size_t)2 * KG * 256 + (MODE != 1 ? 2 * 8 * 256 : 0) + (MODE == 2 ? NT3 * 8 * 256 : 0) + 192) * sizeof(float);
     const int64_t tiles = ((int64_t)a.M + 31) / 32;
     const int64_t per_cu = std::max<int64_t>(1, std::min<int64_t>(mlp_wpc(KG), (160 * 1024) / (int64_t)lds));
     const int64_t blocks = std::min<int64_t>((tiles + 3) / 4, 256 * per_cu);
-    if (a.gidx) hipLaunchKernelGGL((mlp2_kernel<G0, G1, G2, NARROW, true>), dim3((unsigned)blocks), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((mlp2_kernel<G0, G1, G2, NARROW, false>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    if (a.gidx) hipLaunchKernelGGL((mlp2_kernel<G0, G1, G2, NARROW, true, MODE, NT3>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((mlp2_kernel<G0, G1, G2, NARROW, false, MODE, NT3>), dim3((unsigned)blocks), dim3(256), lds, st, a);
     return hipGetLastError();
 }
 
 }  // namespace mlpf
 
+// Layers present: W2 == NULL -> the first layer only; Wm != NULL -> the two heads on y2 as well.
 // -> hipErrorNotSupported for anything but: 64 hidden and output features, >= 2048 rows, pieces as described above in one of the
-// instantiated width combinations, 16-byte aligned y1 / y2 rows (the caller then runs the block layer by layer).
-extern "C" hipError_t dn_mlp2_fused(int64_t M, int npieces, const float *const *x, const int64_t *ldx, const int32_t *K, const int32_t *cols,
-                                    const float *W1, int64_t ldw1, const float *b1, int N1, const int32_t *gidx, int gcol, int act1,
-                                    float slope1, const float *W2, int64_t ldw2, const float *b2, int N2, int act2, float slope2, float *y1,
-                                    int64_t ldy1, float *y2, int64_t ldy2, hipStream_t st) {
-    if (N1 != 64 || N2 != 64 || M < 2048 || npieces < 1 || npieces > 3) return hipErrorNotSupported;
-    if ((ldy1 & 3) || (ldy2 & 3) || ldy1 < 64 || ldy2 < 64 || ((reinterpret_cast<uintptr_t>(y1) | reinterpret_cast<uintptr_t>(y2)) & 15))
-        return hipErrorNotSupported;
-    if (gcol < 0 || ldw1 > 4096 || M * std::max(ldy1, ldy2) * 4 >= 0x7fffffffLL) return hipErrorNotSupported;
+// instantiated width combinations, 16-byte aligned output rows (the caller then runs the block layer by layer).
+extern "C" hipError_t dn_mlp_chain_fused(int64_t M, int npieces, const float *const *x, const int64_t *ldx, const int32_t *K,
+                                         const int32_t *cols, const float *W1, int64_t ldw1, const float *b1, int N1, const int32_t *gidx,
+                                         int gcol, int act1, float slope1, const float *W2, int64_t ldw2, const float *b2, int N2, int act2,
+                                         float slope2, float *y1, int64_t ldy1, float *y2, int64_t ldy2, const float *Wm, int64_t ldwm,
+                                         const float *bm, const float *Wl, int64_t ldwl, const float *bl, int Z, float *mu, int64_t ldmu,
+                                         float *lv, int64_t ldlv, hipStream_t st) {
+    const int mode = !W2 ? 1 : (Wm ? 2 : 0);
+    if (N1 != 64 || (mode != 1 && N2 != 64) || M < 2048 || npieces < 1 || npieces > 3) return hipErrorNotSupported;
+    if (mode == 1 && Wm) return hipErrorNotSupported;
+    if ((ldy1 & 3) || ldy1 < 64 || (reinterpret_cast<uintptr_t>(y1) & 15) || M * ldy1 * 4 >= 0x7fffffffLL) return hipErrorNotSupported;
+    if (mode != 1 && ((ldy2 & 3) || ldy2 < 64 || (reinterpret_cast<uintptr_t>(y2) & 15) || M * ldy2 * 4 >= 0x7fffffffLL)) return hipErrorNotSupported;
+    if (gcol < 0 || ldw1 > 4096) return hipErrorNotSupported;
+    int nt3 = 1;
+    if (mode == 2) {
+        if (!Wl || !mu || !lv || Z < 1 || 2 * Z > 64 || ldmu < Z || ldlv < Z || M * std::max(ldmu, ldlv) * 4 >= 0x7fffffffLL) return hipErrorNotSupported;
+        if ((Z & 3) == 0 && ((ldmu & 3) || (ldlv & 3) || ((reinterpret_cast<uintptr_t>(mu) | reinterpret_cast<uintptr_t>(lv)) & 15)))
+            return hipErrorNotSupported;
+        nt3 = (2 * Z + 31) / 32;
+    }
     int G[3] = {0, 0, 0};
     const bool narrow = K[0] <= 4;
     for (int i = 0; i < npieces; ++i) {
@@ -230,15 +311,31 @@ extern "C" hipError_t dn_mlp2_fused(int64_t M, int npieces, const float *const *
     }
     mlpf::Args a{x[0], npieces > 1 ? x[1] : nullptr, npieces > 2 ? x[2] : nullptr, ldx[0], npieces > 1 ? ldx[1] : 0, npieces > 2 ? ldx[2] : 0,
                  K[0], cols[0], npieces > 1 ? cols[1] : 0, npieces > 2 ? cols[2] : 0, W1, ldw1, b1, gidx, gcol, W2, ldw2, b2, y1, ldy1, y2, ldy2,
-                 (int)M, act1, act2, slope1, slope2};
-#define MLP_CASE(A, B, C, NARROW_)                                                                 \
-    if (G[0] == A && G[1] == B && G[2] == C && narrow == NARROW_) return mlpf::launch<A, B, C, NARROW_>(a, st);
-    MLP_CASE(1, 0, 0, true)      // phi_x: x_t
-    MLP_CASE(2, 0, 0, false)     // phi_z, z_dim 16
-    MLP_CASE(4, 0, 0, false)     // phi_z, z_dim 32
-    MLP_CASE(8, 0, 0, false)     // prior: h
-    MLP_CASE(8, 8, 0, false)     // enc: phi_x, h;  A-VRNN / VRNN dec: phi_z, h
-    MLP_CASE(1, 8, 8, true)      // DAG-Net dec: disposition, phi_z, h
+                 (int)M, act1, act2, slope1, slope2, Wm, Wl, ldwm, ldwl, bm, bl, Z, mu, lv, ldmu, ldlv};
+#define MLP_CASE(A, B, C, NARROW_, MODE_, NT3_)                                                                    \
+    if (G[0] == A && G[1] == B && G[2] == C && narrow == NARROW_ && mode == MODE_ && nt3 == NT3_)                 \
+        return mlpf::launch<A, B, C, NARROW_, MODE_, NT3_>(a, st);
+    MLP_CASE(1, 0, 0, true, 0, 1)      // phi_x: x_t
+    MLP_CASE(2, 0, 0, false, 0, 1)     // phi_z, z_dim 16
+    MLP_CASE(4, 0, 0, false, 0, 1)     // phi_z, z_dim 32
+    MLP_CASE(8, 0, 0, false, 0, 1)     // prior: h
+    MLP_CASE(8, 8, 0, false, 0, 1)     // enc: phi_x, h;  A-VRNN / VRNN dec: phi_z, h
+    MLP_CASE(1, 8, 8, true, 0, 1)      // DAG-Net dec: disposition, phi_z, h
+    MLP_CASE(8, 8, 0, false, 1, 1)     // lg_hiddens / lg: graph output, h (one layer)
+    MLP_CASE(8, 0, 0, false, 2, 1)     // prior + heads, z_dim 16
+    MLP_CASE(8, 0, 0, false, 2, 2)     // prior + heads, z_dim 32
+    MLP_CASE(8, 8, 0, false, 2, 1)     // enc + heads, z_dim 16; A-VRNN / VRNN dec + heads (x_dim 2)
+    MLP_CASE(8, 8, 0, false, 2, 2)     // enc + heads, z_dim 32
+    MLP_CASE(1, 8, 8, true, 2, 1)      // DAG-Net dec + heads (x_dim 2)
 #undef MLP_CASE
     return hipErrorNotSupported;
+}
+
+extern "C" hipError_t dn_mlp2_fused(int64_t M, int npieces, const float *const *x, const int64_t *ldx, const int32_t *K, const int32_t *cols,
+                                    const float *W1, int64_t ldw1, const float *b1, int N1, const int32_t *gidx, int gcol, int act1,
+                                    float slope1, const float *W2, int64_t ldw2, const float *b2, int N2, int act2, float slope2, float *y1,
+                                    int64_t ldy1, float *y2, int64_t ldy2, hipStream_t st) {
+    if (!W2) return hipErrorNotSupported;
+    return dn_mlp_chain_fused(M, npieces, x, ldx, K, cols, W1, ldw1, b1, N1, gidx, gcol, act1, slope1, W2, ldw2, b2, N2, act2, slope2, y1, ldy1,
+                              y2, ldy2, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, st);
 }

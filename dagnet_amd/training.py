@@ -63,6 +63,14 @@ def _mlp2(seq, xs, cols, gidx=None, gcol=0, gdim=0):
     return linear(seq[2], [h], [0], act=ACT_LRELU)
 
 
+def _mlp2_heads(seq, mean, logvar, xs, cols, gidx=None, gcol=0, gdim=0):
+    """-> (block output as a fan-out alias, mean, logvar): the block and its two heads in one kernel."""
+    if len(xs) <= 3:
+        return _ops.mlp2(seq, xs, cols, act=ACT_LRELU, gidx=gidx, gcol=gcol, gdim=gdim, heads=(mean, logvar))
+    out = _ops.fanout(_mlp2(seq, xs, cols, gidx, gcol, gdim))
+    return out, linear(mean, [out], [0]), linear(logvar, [out], [0])
+
+
 def _graph(mod, x, adj_t, plan, stacks=None):
     from .gat import GAT
     return gat_train(mod, x, adj_t, plan, stacks) if isinstance(mod, GAT) else gcn_train(mod, x, adj_t, plan)
@@ -133,31 +141,29 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
                     c_rows.append(CeFn.apply(g_comb, g_t))
             with br.fork("prior", dev):             # prior: joins at the latent draw
                 if kind == "dagnet":
-                    prior = fan(_mlp2(model.prior, [hl], [G], gidx=g_t, gcol=0, gdim=G))
+                    _, mu_p, lv_p = _mlp2_heads(model.prior, model.prior_mean, model.prior_logvar, [hl], [G], gidx=g_t, gcol=0, gdim=G)
                 else:
-                    prior = fan(_mlp2(model.prior, [hl], [0]))
-                mu_p, lv_p = linear(model.prior_mean, [prior], [0]), linear(model.prior_logvar, [prior], [0])
+                    _, mu_p, lv_p = _mlp2_heads(model.prior, model.prior_mean, model.prior_logvar, [hl], [0])
             phi_x = fan(_mlp2(model.phi_x, [x_t], [0]))
             if kind == "dagnet":
-                enc = fan(_mlp2(model.enc, [phi_x, hl], [0, H + G], gidx=g_t, gcol=H, gdim=G))
+                _, mu_e, lv_e = _mlp2_heads(model.enc, model.enc_mean, model.enc_logvar, [phi_x, hl], [0, H + G], gidx=g_t, gcol=H, gdim=G)
             else:
-                enc = fan(_mlp2(model.enc, [phi_x, hl], [0, H]))
-            mu_e, lv_e = linear(model.enc_mean, [enc], [0]), linear(model.enc_logvar, [enc], [0])
+                _, mu_e, lv_e = _mlp2_heads(model.enc, model.enc_mean, model.enc_logvar, [phi_x, hl], [0, H])
             br.join("prior", device=dev)
             z, k = VaeFn.apply(mu_e, lv_e, mu_p, lv_p, _eps(eps, t, N, Z, dev))
             k_rows.append(k)
             phi_z = fan(_mlp2(model.phi_z, [z], [0]))
             with br.fork("dec", dev):               # decoder: ends in the NLL rows
                 if kind == "dagnet":
-                    dec = fan(_mlp2(model.dec, [d_t, phi_z, hl], [0, D + G, D + G + H], gidx=g_t, gcol=D, gdim=G))
+                    _, mu_d, lv_d = _mlp2_heads(model.dec, model.dec_mean, model.dec_logvar, [d_t, phi_z, hl], [0, D + G, D + G + H],
+                                                gidx=g_t, gcol=D, gdim=G)
                 else:
-                    dec = fan(_mlp2(model.dec, [phi_z, hl], [0, H]))
-                mu_d, lv_d = linear(model.dec_mean, [dec], [0]), linear(model.dec_logvar, [dec], [0])
+                    _, mu_d, lv_d = _mlp2_heads(model.dec, model.dec_mean, model.dec_logvar, [phi_z, hl], [0, H])
                 n_rows.append(NllFn.apply(mu_d, lv_d, x_t))
             h = gru_step(model.rnn, [phi_x, phi_z], [0, H], h, packs)
             if kind != "vrnn":
                 h_g = _graph(graph, h[-1], adj[t], plan, st_hid)
-                h[-1] = fan(linear(blend, [h_g, h[-1]], [0, R]))
+                h[-1] = fan(_ops.linear_pieces(blend, [h_g, h[-1]], [0, R]))
         br.join(device=dev)
         zero = torch.zeros(1, dtype=torch.float32, device=dev)
         kld = LossSumFn.apply(1.0 / N, *k_rows) if k_rows else zero

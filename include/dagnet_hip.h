@@ -244,6 +244,14 @@ int dagnet_op_mlp2_fwd(int64_t M, int32_t npieces, const float *const *x, const 
                        const float *W1, int64_t ldw1, const float *b1, int32_t N1, const int32_t *gidx, int32_t gcol, int32_t act1,
                        float slope1, const float *W2, int64_t ldw2, const float *b2, int32_t N2, int32_t act2, float slope2, float *y1,
                        int64_t ldy1, float *y2, int64_t ldy2, void *stream);
+/* dagnet_op_mlp2_fwd with optional layers: W2 = NULL stops after y1 (lg_hiddens / lg: a Linear over [graph output | h],
+ * models/dagnet/model.py:96,190); Wm, Wl != NULL append the two heads that read y2, mu = y2 Wm^T + bm and lv = y2 Wl^T + bl, [M,Z]
+ * each (enc_mean / enc_logvar, prior_*, dec_*: model.py:75-76,83-84,92-93), as a third product of the same kernel. */
+int dagnet_op_mlp_chain_fwd(int64_t M, int32_t npieces, const float *const *x, const int64_t *ldx, const int32_t *K, const int32_t *cols,
+                            const float *W1, int64_t ldw1, const float *b1, int32_t N1, const int32_t *gidx, int32_t gcol, int32_t act1,
+                            float slope1, const float *W2, int64_t ldw2, const float *b2, int32_t N2, int32_t act2, float slope2, float *y1,
+                            int64_t ldy1, float *y2, int64_t ldy2, const float *Wm, int64_t ldwm, const float *bm, const float *Wl,
+                            int64_t ldwl, const float *bl, int32_t Z, float *mu, int64_t ldmu, float *lv, int64_t ldlv, void *stream);
 /* Replaces: one layer of nn.GRU at seq_len = 1 from its inputs (models/dagnet/model.py:109-110,:186): gi = [x0 | x1] W_ih^T + b_ih,
  * gh = h W_hh^T + b_hh and the gate arithmetic in one call (x1 = NULL, K1 = 0: a single input piece).  gi, gh [M,3R], hn [M,R],
  * gates [M,3R] are contiguous.  rnn_dim 64 with 64-wide pieces and >= 2048 rows runs as ONE kernel (csrc/gru_fused.hip) that

@@ -222,3 +222,56 @@ def test_mlp2_matches_torch(M, pieces, gather):
     r2 = torch.nn.functional.leaky_relu(r1 @ W2.double().t() + b2.double(), 0.01)
     torch.testing.assert_close(y1.double(), r1, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(y2.double(), r2, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,pieces,gather,Z", [(4100, (64, 64), True, 32), (3000, (64, 64), False, 16), (2500, (64,), True, 32), (5000, (64,), False, 16),
+                                               (3100, (2, 64, 64), True, 2), (2200, (64, 64), False, 2), (100, (64, 64), True, 32),
+                                               (2600, (64, 64), False, 0), (3000, (32,), False, 32)])
+def test_mlp_chain_matches_torch(M, pieces, gather, Z):
+    """dagnet_op_mlp_chain_fwd: block + the two heads on its output (Z > 0), or the first layer alone over two pieces (Z = 0), one
+    kernel for the instantiated shapes and layer by layer otherwise (M = 100, the (32,) block with heads)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(M + 7 * sum(pieces) + int(gather) + Z)
+    G = 90 if gather else 0
+    cols, c = [], 0
+    for i, k in enumerate(pieces):
+        cols.append(c)
+        c += k + (G if i == 0 else 0)
+    gcol, Ktot = pieces[0], c
+    xs = [torch.randn((M, k), generator=g).to(DEV) for k in pieces]
+    W1, b1 = (torch.randn((64, Ktot), generator=g) / Ktot ** 0.5).to(DEV), torch.randn(64, generator=g).to(DEV)
+    W2, b2 = (torch.randn((64, 64), generator=g) / 8).to(DEV), torch.randn(64, generator=g).to(DEV)
+    Wm, Wl = (torch.randn((max(Z, 1), 64), generator=g) / 8).to(DEV), (torch.randn((max(Z, 1), 64), generator=g) / 8).to(DEV)
+    bm, bl = torch.randn(max(Z, 1), generator=g).to(DEV), torch.randn(max(Z, 1), generator=g).to(DEV)
+    gidx = torch.randint(0, G, (M,), generator=g).to(torch.int32).to(DEV) if gather else None
+    y1, y2 = torch.full((M, 64), float("nan"), device=DEV), torch.full((M, 64), float("nan"), device=DEV)
+    mu, lv = torch.full((M, max(Z, 1)), float("nan"), device=DEV), torch.full((M, max(Z, 1)), float("nan"), device=DEV)
+    n = len(xs)
+    ptr = (C.c_void_p * n)(*[x.data_ptr() for x in xs])
+    ldx = (C.c_int64 * n)(*[x.stride(0) for x in xs])
+    ks, cs = (C.c_int32 * n)(*pieces), (C.c_int32 * n)(*cols)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    act1 = _ops.ACT_LRELU if Z else _ops.ACT_NONE
+    heads = Z > 0
+    _ops._check(_ops._lib().dagnet_op_mlp_chain_fwd(
+        M, n, ptr, ldx, ks, cs, p(W1), Ktot, p(b1), 64, p(gidx), gcol, act1, 0.01, p(W2) if heads else None, 64, p(b2) if heads else None,
+        64 if heads else 0, _ops.ACT_LRELU, 0.01, p(y1), 64, p(y2) if heads else None, 64, p(Wm) if heads else None, 64, p(bm) if heads else None,
+        p(Wl) if heads else None, 64, p(bl) if heads else None, Z, p(mu) if heads else None, max(Z, 1), p(lv) if heads else None, max(Z, 1),
+        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    full = torch.zeros((M, Ktot), dtype=torch.float64, device=DEV)
+    for x, c0 in zip(xs, cols):
+        full[:, c0:c0 + x.shape[1]] = x.double()
+    if gather:
+        full[torch.arange(M, device=DEV), gcol + gidx.long()] = 1.0
+    r1 = full @ W1.double().t() + b1.double()
+    tol = dict(rtol=2e-5, atol=2e-5)
+    if not heads:
+        torch.testing.assert_close(y1.double(), r1, **tol)
+        assert torch.isnan(y2).all()
+        return
+    r1 = torch.nn.functional.leaky_relu(r1, 0.01)
+    r2 = torch.nn.functional.leaky_relu(r1 @ W2.double().t() + b2.double(), 0.01)
+    torch.testing.assert_close(y1.double(), r1, **tol)
+    torch.testing.assert_close(y2.double(), r2, **tol)
+    torch.testing.assert_close(mu.double(), r2 @ Wm.double().t() + bm.double(), **tol)
+    torch.testing.assert_close(lv.double(), r2 @ Wl.double().t() + bl.double(), **tol)

@@ -22,7 +22,7 @@ ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
 OP_EXPORTS = (
     "dagnet_op_gemm", "dagnet_op_gemm_dact", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
-    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_mlp_chain_fwd", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
+    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_mlp_chain_fwd", "dagnet_op_mlp2_bwd", "dagnet_op_set_fused", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
     "dagnet_op_gat_attn_fwd", "dagnet_op_gat_attn_bwd", "dagnet_op_adj_matmul", "dagnet_op_disposition", "dagnet_op_sumsq",
@@ -56,6 +56,9 @@ def _lib():
                                            vp, i64, vp, i64, vp]
         lib.dagnet_op_mlp_chain_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, i64, vp, i32, vp, i32, i32, C.c_float, vp, i64, vp, i32, i32, C.c_float,
                                                 vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i32, vp, i64, vp, i64, vp]
+        f32 = C.c_float
+        lib.dagnet_op_mlp2_bwd.argtypes = [i64, vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, f32, vp, i64, i32, f32,
+                                           vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, i32, i32, vp]
         lib.dagnet_op_gru_pack.argtypes = [i32, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]
         lib.dagnet_op_gru_pack_floats.argtypes = [i32, i32, i32]
         lib.dagnet_op_gru_pack_floats.restype = i64
@@ -132,6 +135,12 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
     if t.dim() == 2 and (t.shape[1] <= 1 or t.stride(1) == 1) and (t.shape[0] <= 1 or t.stride(0) >= t.shape[1]):
         return t
     return t.contiguous()
+
+
+def set_fused(mask: int) -> int:
+    """Select the fused training kernels (bit 0 GRU layer forward, 1 dense blocks forward, 2 dense blocks backward; < 0: default).
+    -> the previous mask."""
+    return int(_lib().dagnet_op_set_fused(int(mask)))
 
 
 def gemm(A, B, C_out, *, transb=False, bias=None, act=ACT_NONE, slope=0.01, accumulate=False, gather=None, gidx=None, gs_g=0, gs_n=0,
@@ -466,10 +475,13 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(W, y, gidx, *xs)
         ctx.W_param, ctx.b_param = W, b          # the leaf parameters themselves (for their gradient sinks)
         ctx.meta = (act, slope, tuple(cols), gcol, gdim, b is not None)
+        ctx.set_materialize_grads(False)       # a lazy node may get no gradient at all (its block's backward ran as one kernel)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:                   # a lazy node whose block ran its backward as one kernel (MlpChainFn)
+            return (None,) * (8 + len(ctx.saved_tensors) - 3)
         W, y, gidx, *xs = ctx.saved_tensors
         act, slope, cols, gcol, gdim, has_b = ctx.meta
         N, Ktot = W.shape
@@ -550,6 +562,7 @@ class MlpChainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y1, y2, mu, lv, l1, l2, heads, act, slope, cols, gidx, gcol, *xs):
+        gcol, ctx.gdim = gcol if isinstance(gcol, tuple) else (gcol, 0)
         M = y1.shape[0]
         n = len(xs)
         for x in xs:
@@ -576,6 +589,11 @@ class MlpChainFn(torch.autograd.Function):
         ctx.n_in = 12 + n
         ctx.has = (y2 is not None, heads is not None)
         ctx.set_materialize_grads(False)
+        if y2 is not None:               # what the one-kernel backward needs (the unfused one keeps its own records in the lazy nodes)
+            ctx.slot = POOL.site()
+            ctx.blk = (l1, l2, heads, act, slope, tuple(cols), gidx, gcol, mu.shape[1] if heads is not None else 0)
+            ctx.xs, ctx.y12 = xs, (y1, y2)
+            ctx.gaccs = [_gacc_of(x) for x in xs]
         last = y2 if y2 is not None else y1
         if heads is not None:
             return last.view_as(last), mu.view_as(mu), lv.view_as(lv)
@@ -585,10 +603,81 @@ class MlpChainFn(torch.autograd.Function):
     def backward(ctx, *g):
         two, heads = ctx.has
         out = [None] * ctx.n_in
+        if two and MlpChainFn._fused_backward(ctx, g, out):
+            return tuple(out)
         out[1 if two else 0] = g[0]
         if heads:
             out[2], out[3] = g[1], g[2]
         return tuple(out)
+
+    @staticmethod
+    def _fused_backward(ctx, g, out):
+        """One kernel from (dmu, dlv | dy2) to the pieces' input gradients; the weight gradients are recorded for the deferred
+        products exactly as LinearFn.backward records them.  -> False (nothing done) when a piece of the bookkeeping is missing
+        (no gradient arena, an input piece whose gradient has nowhere to go, an unsupported shape)."""
+        (W1, b1), (W2, b2), hd, act, slope, cols, gidx, gcol, Z = ctx.blk
+        xs, (y1, y2) = ctx.xs, ctx.y12
+        heads = hd is not None
+        layers = [(W1, b1), (W2, b2)] + ([hd[0], hd[1]] if heads else [])
+        for (W, b) in layers:
+            if _sink(W) is None or _defer(W) is None or (b is not None and _sink(b) is None):
+                return False
+        if heads:
+            dmu, dlv = g[1], g[2]
+            if dmu is None or dlv is None or g[0] is not None:
+                return False
+            dmu, dlv = _rows(dmu), _rows(dlv)
+        else:
+            if g[0] is None:
+                return False
+            dy2 = _rows(g[0])
+        M = y1.shape[0]
+        want = [i for i in range(len(xs)) if ctx.needs_input_grad[12 + i]]
+        if len(want) > 2 or any(xs[i].shape[1] % 4 or xs[i].shape[1] > 64 for i in want):
+            return False
+        dp2, dp1 = POOL.at(ctx.slot, "dpre2", (M, 64), y1), POOL.at(ctx.slot, "dpre1", (M, 64), y1)
+        dst = []
+        for i in want:
+            gacc = ctx.gaccs[i]
+            if gacc is not None:
+                dst.append((gacc.buffer(xs[i]), int(gacc.started), gacc))
+            else:
+                dst.append((POOL.at(ctx.slot, "dx%d" % i, tuple(xs[i].shape), y1), 0, None))
+        pa = [(None, 0, 0, 0, 0), (None, 0, 0, 0, 0)]
+        for j, i in enumerate(want):
+            (ptr, ld) = _m(dst[j][0], "dx")
+            pa[j] = (ptr, ld, int(cols[i]), xs[i].shape[1], dst[j][1])
+        (w1, ldw1), (w2, ldw2), (py1, ldy1), (py2, ldy2), (pd2, ld2), (pd1, ld1) = _m(W1), _m(W2), _m(y1), _m(y2), _m(dp2), _m(dp1)
+        if heads:
+            (wm, ldwm), (wl, ldwl), (pmu, ldmu), (plv, ldlv) = _m(hd[0][0]), _m(hd[1][0]), _m(dmu), _m(dlv)
+            pdy, lddy = None, 0
+        else:
+            wm = wl = pmu = plv = None
+            ldwm = ldwl = ldmu = ldlv = 0
+            (pdy, lddy) = _m(dy2)
+        rc = _lib().dagnet_op_mlp2_bwd(M, pdy, lddy, pmu, ldmu, plv, ldlv, Z, wm, ldwm, wl, ldwl, py2, ldy2, py1, ldy1, w2, ldw2, act[1], slope,
+                                       w1, ldw1, act[0], slope, pd2, ld2, pd1, ld1, *pa[0], *pa[1], _stream(y1.device))
+        if rc == 1:
+            return False
+        _check(rc)
+        for j, i in enumerate(want):
+            if dst[j][2] is not None:
+                dst[j][2].done()
+            else:
+                out[12 + i] = dst[j][0]
+
+        sink1, defer1 = _sink(W1), _defer(W1)
+        bs1 = _sink(b1) if b1 is not None else None
+        for s_, (x, c0) in enumerate(zip(xs, cols)):
+            defer1.add((id(W1), c0), dp1, x, sink1[:, c0:c0 + x.shape[1]], bias_dst=bs1 if s_ == 0 else None)
+        if gidx is not None:
+            gdim = ctx.gdim
+            defer1.add((id(W1), gcol), dp1, None, sink1[:, gcol:gcol + gdim], gidx=gidx)
+        _defer(W2).add((id(W2), 0), dp2, y1, _sink(W2), bias_dst=_sink(b2) if b2 is not None else None)
+        if heads:
+            for (W, b), d in ((hd[0], dmu), (hd[1], dlv)):
+                _defer(W).add((id(W), 0), d, y2, _sink(W), bias_dst=_sink(b) if b is not None else None)
+        return True
 
 
 def mlp2(seq, xs, cols, act=ACT_LRELU, slope=0.01, gidx=None, gcol=0, gdim=0, heads=None):
@@ -609,9 +698,9 @@ def mlp2(seq, xs, cols, act=ACT_LRELU, slope=0.01, gidx=None, gcol=0, gdim=0, he
         _LAZY_LINEAR = False
     w = ((l1.weight, l1.bias), (l2.weight, l2.bias))
     if heads is None:
-        return MlpChainFn.apply(y1, y2, None, None, w[0], w[1], None, (act, act), slope, tuple(cols), gidx, gcol, *xs)
+        return MlpChainFn.apply(y1, y2, None, None, w[0], w[1], None, (act, act), slope, tuple(cols), gidx, (gcol, gdim), *xs)
     hw = ((heads[0].weight, heads[0].bias), (heads[1].weight, heads[1].bias))
-    _, mu_a, lv_a = MlpChainFn.apply(y1, y2, mu, lv, w[0], w[1], hw, (act, act), slope, tuple(cols), gidx, gcol, *xs)
+    _, mu_a, lv_a = MlpChainFn.apply(y1, y2, mu, lv, w[0], w[1], hw, (act, act), slope, tuple(cols), gidx, (gcol, gdim), *xs)
     return out, mu_a, lv_a
 
 

@@ -1,6 +1,7 @@
 // Host side of libdagnet_hip.so: weight re-packing into MFMA fragment order, scene->tile planning,
 // LDS layout, argument checks and the extern "C" entry points declared in include/dagnet_hip.h.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdarg.h>
 #include <stddef.h>
 #include <stdio.h>
@@ -1655,6 +1656,26 @@ extern "C" int dagnet_op_gru_fwd(int64_t M, int32_t R, const float *gi, const fl
     HIP_TRY(dn_t_gru_fwd(M, R, gi, gh, h, hn, gates, OP_ST));
     return DAGNET_OK;
 }
+// Which of the fused training kernels are in use (bit 0: GRU layer forward, 1: dense blocks forward, 2: dense blocks backward).
+// All on unless DAGNET_NO_GRU_FUSED / DAGNET_NO_MLP_FUSED / DAGNET_NO_MLP_BWD_FUSED is set; dagnet_op_set_fused changes it at run
+// time (the tests compare a training step with and without them).
+static int fused_default() {
+    return (getenv("DAGNET_NO_GRU_FUSED") ? 0 : 1) | (getenv("DAGNET_NO_MLP_FUSED") ? 0 : 2) | (getenv("DAGNET_NO_MLP_BWD_FUSED") ? 0 : 4);
+}
+static std::atomic<int> g_fused{-1};
+static int fused_mask() {
+    int m = g_fused.load(std::memory_order_relaxed);
+    if (m < 0) {
+        m = fused_default();
+        g_fused.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+extern "C" int dagnet_op_set_fused(int32_t mask) {
+    const int before = fused_mask();
+    g_fused.store(mask < 0 ? fused_default() : (mask & 7), std::memory_order_relaxed);
+    return before;
+}
 extern "C" hipError_t dn_gru_fused_fwd(int64_t M, int R, int npieces, const float *x0, int64_t ldx0, const float *x1, int64_t ldx1,
                                        const float *h, int64_t ldh, const float *Wih, int64_t ldwih, const float *bih, const float *Whh,
                                        int64_t ldwhh, const float *bhh, float *hn, int64_t ldhn, float *gates, int64_t ldg, float *gh,
@@ -1681,7 +1702,7 @@ extern "C" int dagnet_op_gru_layer_fwd(int64_t M, int32_t R, const float *x0, in
     OP_NEED(M >= 0 && R >= 1 && K0 >= 1 && K1 >= 0 && M < 0x7fffffffLL, "bad argument");
     if (M == 0) return DAGNET_OK;
     OP_NEED(x0 && (K1 == 0 || x1) && h && Wih && Whh && gi && gh && hn && gates, "null operand");
-    static const bool no_fused = getenv("DAGNET_NO_GRU_FUSED") != nullptr;
+    const bool no_fused = !(fused_mask() & 1);
     if (!no_fused && K0 == 64 && (K1 == 0 || K1 == 64)) {
         const hipError_t e = dn_gru_fused_fwd(M, R, K1 ? 2 : 1, x0, ldx0, x1, ldx1, h, ldh, Wih, ldwih, bih, Whh, ldwhh, bhh, hn, R, gates,
                                               3 * R, gh, 3 * R, pack, OP_ST);
@@ -1725,7 +1746,7 @@ extern "C" int dagnet_op_mlp_chain_fwd(int64_t M, int32_t npieces, const float *
     OP_NEED(W1 && y1 && (!W2 || (y2 && N2 >= 1)), "null operand");
     OP_NEED((!Wm && !Wl) || (W2 && Wm && Wl && mu && lv && Z >= 1), "heads need both weight matrices, both outputs and the second layer");
     for (int i = 0; i < npieces; ++i) OP_NEED(x[i] && K[i] >= 1, "null or empty input piece");
-    static const bool no_fused = getenv("DAGNET_NO_MLP_FUSED") != nullptr;
+    const bool no_fused = !(fused_mask() & 2);
     if (!no_fused) {
         const hipError_t e = dn_mlp_chain_fused(M, npieces, x, ldx, K, cols, W1, ldw1, b1, N1, gidx, gcol, act1, slope1, W2, ldw2, b2, N2, act2,
                                                 slope2, y1, ldy1, y2, ldy2, Wm, ldwm, bm, Wl, ldwl, bl, Z, mu, ldmu, lv, ldlv, OP_ST);
@@ -1743,6 +1764,30 @@ extern "C" int dagnet_op_mlp_chain_fwd(int64_t M, int32_t npieces, const float *
         HIP_TRY(dn_gemm(y2, ldy2, Wm, ldwm, 0, bm, mu, ldmu, (int)M, Z, N2, 0, 0.f, 0, nullptr, nullptr, 0, 0, OP_ST));
         HIP_TRY(dn_gemm(y2, ldy2, Wl, ldwl, 0, bl, lv, ldlv, (int)M, Z, N2, 0, 0.f, 0, nullptr, nullptr, 0, 0, OP_ST));
     }
+    return DAGNET_OK;
+}
+extern "C" hipError_t dn_mlp2_bwd_fused(int64_t M, const float *dy2, int64_t lddy2, const float *dmu, int64_t lddmu, const float *dlv,
+                                        int64_t lddlv, int Z, const float *Wm, int64_t ldwm, const float *Wl, int64_t ldwl,
+                                        const float *y2, int64_t ldy2, const float *y1, int64_t ldy1, const float *W2, int64_t ldw2,
+                                        int act2, float slope2, const float *W1, int64_t ldw1, int act1, float slope1, float *dp2,
+                                        int64_t lddp2, float *dp1, int64_t lddp1, float *dxA, int64_t lddxA, int cA, int KA, int accA,
+                                        float *dxB, int64_t lddxB, int cB, int KB, int accB, hipStream_t st);
+// Backward of a two-layer block from the gradients at its heads (dy2 = NULL) or at its output: dpre2, dpre1 (the operands of the
+// layers' weight gradients) and the input gradients of up to two pieces.  -> DAGNET_OK, or 1 when this shape has no fused kernel
+// (nothing written: the caller runs the backward layer by layer).
+extern "C" int dagnet_op_mlp2_bwd(int64_t M, const float *dy2, int64_t lddy2, const float *dmu, int64_t lddmu, const float *dlv,
+                                  int64_t lddlv, int32_t Z, const float *Wm, int64_t ldwm, const float *Wl, int64_t ldwl, const float *y2,
+                                  int64_t ldy2, const float *y1, int64_t ldy1, const float *W2, int64_t ldw2, int32_t act2, float slope2,
+                                  const float *W1, int64_t ldw1, int32_t act1, float slope1, float *dp2, int64_t lddp2, float *dp1,
+                                  int64_t lddp1, float *dxA, int64_t lddxA, int32_t cA, int32_t KA, int32_t accA, float *dxB,
+                                  int64_t lddxB, int32_t cB, int32_t KB, int32_t accB, void *stream) {
+    OP_NEED(M >= 0, "bad argument");
+    if (!(fused_mask() & 4) || M == 0) return 1;
+    const hipError_t e = dn_mlp2_bwd_fused(M, dy2, lddy2, dmu, lddmu, dlv, lddlv, Z, Wm, ldwm, Wl, ldwl, y2, ldy2, y1, ldy1, W2, ldw2, act2,
+                                           slope2, W1, ldw1, act1, slope1, dp2, lddp2, dp1, lddp1, dxA, lddxA, cA, KA, accA, dxB, lddxB, cB,
+                                           KB, accB, OP_ST);
+    if (e == hipErrorNotSupported) return 1;
+    HIP_TRY(e);
     return DAGNET_OK;
 }
 extern "C" int dagnet_op_gru_bwd(int64_t M, int32_t R, const float *dhn, const float *gates, const float *gh, const float *h, float *dgi,

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <type_traits>
 
 namespace mlpf {
 
@@ -338,4 +339,245 @@ extern "C" hipError_t dn_mlp2_fused(int64_t M, int npieces, const float *const *
     if (!W2) return hipErrorNotSupported;
     return dn_mlp_chain_fused(M, npieces, x, ldx, K, cols, W1, ldw1, b1, N1, gidx, gcol, act1, slope1, W2, ldw2, b2, N2, act2, slope2, y1, ldy1,
                               y2, ldy2, nullptr, 0, nullptr, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0, st);
+}
+
+// =================================================================================================
+// Backward of a two-layer block (and its heads) as ONE kernel: everything between the gradients that arrive at the block -
+// dmu, dlv at the heads, or dy2 at the block's output - and the gradients of its input pieces:
+//     d y2 = dmu Wm + dlv Wl            (heads)          dpre2 = d y2 * act2'(y2)       -> written (weight gradient of layer 2)
+//     d y1 = dpre2 W2                                    dpre1 = d y1 * act1'(y1)       -> written (weight gradient of layer 1)
+//     dx_s (+)= dpre1 W1[:, c_s : c_s + K_s]             for up to two input pieces that need a gradient
+// Layer by layer these are 4 - 6 launches that pass d y2, dpre2, d y1, dpre1 through HBM between them.  The same register trick as
+// in the forward pass carries the chain: a product's accumulators (lane = row, 4 consecutive features per register quad) are the
+// next product's operand quads; the transposed weight matrices sit in LDS in MFMA operand order.
+// =================================================================================================
+namespace mlpf {
+
+struct BArgs {
+    const float *dy2; int64_t lddy2;                       // G3 == 0: gradient of the block output [M, 64]
+    const float *dmu, *dlv; int64_t lddmu, lddlv; int Z;   // heads: [M, Z] each
+    const float *Wm, *Wl; int64_t ldwm, ldwl;              // [Z, 64]
+    const float *y2, *y1; int64_t ldy2, ldy1;              // saved outputs [M, 64]
+    const float *W2; int64_t ldw2;                         // [64, 64]
+    const float *W1; int64_t ldw1; int cA, cB, KA, KB;     // [64, Ktot]; columns and widths of the pieces that need a gradient
+    float *dp2, *dp1; int64_t lddp2, lddp1;                // [M, 64] each
+    float *dxA, *dxB; int64_t lddxA, lddxB; int accA, accB;
+    int M, act1, act2; float slope1, slope2;
+};
+
+__device__ __forceinline__ float act_grad(int act, float y, float slope) {
+    if (act == ACT_LRELU) return y > 0.f ? 1.f : slope;
+    if (act == ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == ACT_TANH) return 1.f - y * y;
+    return 1.f;
+}
+
+// NTA, NTB: 32-column tiles of the two pieces that get a gradient (0: absent).  G3: 0 = dy2 is given; 4 / 8 = heads with
+// 2 Z = 8 G3 stacked rows (Z = 16 / 32); 1 = narrow heads (2 Z <= 4: the decoder's 2 + 2 outputs, scalar loads).
+template <int NTA, int NTB, int G3>
+__global__ __launch_bounds__(256, 3) void mlp2_bwd_kernel(const BArgs p) {
+    constexpr int G3A = G3 ? G3 : 1;
+    extern __shared__ float lds[];           // w3t [2][G3][64][4] | w2t [2][8][64][4] | wAt [NTA][8][64][4] | wBt [NTB][8][64][4]
+    float *w3t = lds, *w2t = w3t + (G3 ? 2 * G3 * 256 : 0), *wAt = w2t + 2 * 8 * 256, *wBt = wAt + NTA * 8 * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    // ---- transposed weight images: quad (tile nt, group g, lane l), element i = W[k = 8 g + 4 (l >> 5) + i][n = 32 nt + (l & 31)]
+    if constexpr (G3 != 0) {
+        for (int e = tid; e < 2 * G3 * 256; e += 256) {
+            const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) % G3, nt = (e >> 8) / G3;
+            const int k = 8 * g + 4 * (l >> 5) + i, n = nt * 32 + (l & 31);
+            w3t[e] = k < p.Z ? p.Wm[(int64_t)k * p.ldwm + n] : (k < 2 * p.Z ? p.Wl[(int64_t)(k - p.Z) * p.ldwl + n] : 0.f);
+        }
+    }
+    for (int e = tid; e < 2 * 8 * 256; e += 256) {
+        const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 7, nt = e >> 11;
+        w2t[e] = p.W2[(int64_t)(8 * g + 4 * (l >> 5) + i) * p.ldw2 + nt * 32 + (l & 31)];
+    }
+    for (int e = tid; e < NTA * 8 * 256; e += 256) {
+        const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 7, nt = e >> 11, n = nt * 32 + (l & 31);
+        wAt[e] = n < p.KA ? p.W1[(int64_t)(8 * g + 4 * (l >> 5) + i) * p.ldw1 + p.cA + n] : 0.f;
+    }
+    for (int e = tid; e < NTB * 8 * 256; e += 256) {
+        const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 7, nt = e >> 11, n = nt * 32 + (l & 31);
+        wBt[e] = n < p.KB ? p.W1[(int64_t)(8 * g + 4 * (l >> 5) + i) * p.ldw1 + p.cB + n] : 0.f;
+    }
+    __syncthreads();
+
+    const int n_tiles = (p.M + 31) >> 5;
+    const int stride = (int)gridDim.x * 4;
+    const i32x4 rdy = make_rsrc(G3 ? p.y2 : p.dy2, (int64_t)p.M * (G3 ? p.ldy2 : p.lddy2) * 4);
+    const i32x4 rdm = make_rsrc(G3 ? p.dmu : p.y2, (int64_t)p.M * (G3 ? p.lddmu : p.ldy2) * 4);
+    const i32x4 rdl = make_rsrc(G3 ? p.dlv : p.y2, (int64_t)p.M * (G3 ? p.lddlv : p.ldy2) * 4);
+    const i32x4 ry2 = make_rsrc(p.y2, (int64_t)p.M * p.ldy2 * 4), ry1 = make_rsrc(p.y1, (int64_t)p.M * p.ldy1 * 4);
+    const i32x4 rp2 = make_rsrc(p.dp2, (int64_t)p.M * p.lddp2 * 4), rp1 = make_rsrc(p.dp1, (int64_t)p.M * p.lddp1 * 4);
+    const i32x4 rxa = make_rsrc(NTA ? p.dxA : p.dp1, (int64_t)p.M * (NTA ? p.lddxA : p.lddp1) * 4);
+    const i32x4 rxb = make_rsrc(NTB ? p.dxB : p.dp1, (int64_t)p.M * (NTB ? p.lddxB : p.lddp1) * 4);
+    const int ldy24 = (int)p.ldy2 * 4, ldy14 = (int)p.ldy1 * 4, ldp24 = (int)p.lddp2 * 4, ldp14 = (int)p.lddp1 * 4;
+
+    for (int tile = (int)blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
+        const int row = tile * 32 + lr;          // rows past M: loads return 0 and stores are dropped (range check)
+        f32x4 gq[G3A], yq[8], zq[8];
+        // ---- operands of the first product and the saved outputs (same lanes, same features as the accumulators)
+        if constexpr (G3 == 1) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = mf_load1(rdm, (row * (int)p.lddmu + min(i, p.Z - 1)) * 4, 0, 0);
+                const float b = mf_load1(rdl, (row * (int)p.lddlv + min(max(i - p.Z, 0), p.Z - 1)) * 4, 0, 0);
+                v[i] = lh == 0 ? (i < p.Z ? a : (i < 2 * p.Z ? b : 0.f)) : 0.f;
+            }
+            gq[0] = v;
+        } else if constexpr (G3 > 1) {
+#pragma unroll
+            for (int g = 0; g < G3 / 2; ++g) {
+                gq[g] = mf_load4(rdm, row * (int)p.lddmu * 4 + 16 * lh + g * 32, 0, 0);
+                gq[G3 / 2 + g] = mf_load4(rdl, row * (int)p.lddlv * 4 + 16 * lh + g * 32, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            yq[q] = mf_load4(ry2, row * ldy24 + 16 * lh + q * 32, 0, 0);
+            zq[q] = mf_load4(ry1, row * ldy14 + 16 * lh + q * 32, 0, 0);
+        }
+        f32x16 acc[2];
+        f32x4 pq[8];
+        if constexpr (G3 == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) pq[q] = mf_load4(rdy, row * (int)p.lddy2 * 4 + 16 * lh + q * 32, 0, 0);
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+            for (int g = 0; g < G3A; ++g) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(w3t + ((nt * G3A + g) * 64 + lane) * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i], gq[g][i], acc[nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pq[q][i] = acc[q >> 2][4 * (q & 3) + i];
+        }
+        // ---- dpre2 = d y2 * act2'(y2)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pq[q][i] *= act_grad(p.act2, yq[q][i], p.slope2);
+            mf_store4(pq[q], rp2, row * ldp24 + 16 * lh + q * 32, 0, 0);
+        }
+        // ---- d y1 = dpre2 W2, dpre1 = d y1 * act1'(y1)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(w2t + ((nt * 8 + g) * 64 + lane) * 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i], pq[g][i], acc[nt], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pq[q][i] = acc[q >> 2][4 * (q & 3) + i] * act_grad(p.act1, zq[q][i], p.slope1);
+            mf_store4(pq[q], rp1, row * ldp14 + 16 * lh + q * 32, 0, 0);
+        }
+        // ---- input gradients of the pieces
+        auto piece = [&](auto nt_tag, const float *wt, const i32x4 rx, const int ldx4, const int K, const int accum) {
+            constexpr int NTP = decltype(nt_tag)::value;
+            f32x16 ax[NTP ? NTP : 1];
+#pragma unroll
+            for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    if (accum && nt * 32 + 8 * a + 4 * lh < K) c = mf_load4(rx, row * ldx4 + (nt * 32 + 8 * a + 4 * lh) * 4, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ax[nt][4 * a + i] = c[i];
+                }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+#pragma unroll
+                for (int nt = 0; nt < NTP; ++nt) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(wt + ((nt * 8 + g) * 64 + lane) * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ax[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i], pq[g][i], ax[nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int f0 = nt * 32 + 8 * a + 4 * lh;
+                    if (f0 < K) mf_store4(f32x4{ax[nt][4 * a], ax[nt][4 * a + 1], ax[nt][4 * a + 2], ax[nt][4 * a + 3]}, rx, row * ldx4 + f0 * 4, 0, 0);
+                }
+        };
+        if constexpr (NTA > 0) piece(std::integral_constant<int, NTA>{}, wAt, rxa, (int)p.lddxA * 4, p.KA, p.accA);
+        if constexpr (NTB > 0) piece(std::integral_constant<int, NTB>{}, wBt, rxb, (int)p.lddxB * 4, p.KB, p.accB);
+    }
+}
+
+template <int NTA, int NTB, int G3>
+static hipError_t launch_bwd(const BArgs &a, hipStream_t st) {
+    const size_t lds = ((size_t)(G3 ? 2 * G3 * 256 : 0) + 2 * 8 * 256 + (NTA + NTB) * 8 * 256) * sizeof(float);
+    const int64_t tiles = ((int64_t)a.M + 31) / 32;
+    const int64_t blocks = std::min<int64_t>((tiles + 3) / 4, 256 * 3);
+    hipLaunchKernelGGL((mlp2_bwd_kernel<NTA, NTB, G3>), dim3((unsigned)blocks), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace mlpf
+
+// -> hipErrorNotSupported when no instantiation fits (the caller runs the backward layer by layer; nothing has been written).
+// heads: dmu / dlv / Wm / Wl / Z given and dy2 NULL; else dy2 given.  Pieces A, B: dx NULL = no gradient wanted.  Piece widths are
+// multiples of 4 up to 64 with 16-byte rows; all [M, 64] matrices have 16-byte rows.
+extern "C" hipError_t dn_mlp2_bwd_fused(int64_t M, const float *dy2, int64_t lddy2, const float *dmu, int64_t lddmu, const float *dlv,
+                                        int64_t lddlv, int Z, const float *Wm, int64_t ldwm, const float *Wl, int64_t ldwl,
+                                        const float *y2, int64_t ldy2, const float *y1, int64_t ldy1, const float *W2, int64_t ldw2,
+                                        int act2, float slope2, const float *W1, int64_t ldw1, int act1, float slope1, float *dp2,
+                                        int64_t lddp2, float *dp1, int64_t lddp1, float *dxA, int64_t lddxA, int cA, int KA, int accA,
+                                        float *dxB, int64_t lddxB, int cB, int KB, int accB, hipStream_t st) {
+    if (M < 2048 || !y2 || !y1 || !W2 || !W1 || !dp2 || !dp1) return hipErrorNotSupported;
+    const bool heads = dy2 == nullptr;
+    if (heads && (!dmu || !dlv || !Wm || !Wl || Z < 1)) return hipErrorNotSupported;
+    if (dxB && !dxA) return hipErrorNotSupported;
+    auto ok64 = [&](const void *q, int64_t ld) {
+        return q && !(ld & 3) && ld >= 64 && !(reinterpret_cast<uintptr_t>(q) & 15) && M * ld * 4 < 0x7fffffffLL;
+    };
+    if (!ok64(y2, ldy2) || !ok64(y1, ldy1) || !ok64(dp2, lddp2) || !ok64(dp1, lddp1) || (!heads && !ok64(dy2, lddy2))) return hipErrorNotSupported;
+    auto okp = [&](const float *q, int64_t ld, int K) {
+        return !(K & 3) && K >= 4 && K <= 64 && !(ld & 3) && ld >= K && !(reinterpret_cast<uintptr_t>(q) & 15) && M * ld * 4 < 0x7fffffffLL;
+    };
+    if (dxA && !okp(dxA, lddxA, KA)) return hipErrorNotSupported;
+    if (dxB && !okp(dxB, lddxB, KB)) return hipErrorNotSupported;
+    int g3 = 0;
+    if (heads) {
+        if (M * std::max(lddmu, lddlv) * 4 >= 0x7fffffffLL) return hipErrorNotSupported;
+        if (2 * Z <= 4) g3 = 1;
+        else if (Z == 16 || Z == 32) {
+            if ((lddmu & 3) || (lddlv & 3) || ((reinterpret_cast<uintptr_t>(dmu) | reinterpret_cast<uintptr_t>(dlv)) & 15)) return hipErrorNotSupported;
+            g3 = Z / 4;
+        } else return hipErrorNotSupported;
+    }
+    const int nta = dxA ? (KA + 31) / 32 : 0, ntb = dxB ? (KB + 31) / 32 : 0;
+    mlpf::BArgs a{dy2, lddy2, dmu, dlv, lddmu, lddlv, Z, Wm, Wl, ldwm, ldwl, y2, y1, ldy2, ldy1, W2, ldw2, W1, ldw1, cA, cB, KA, KB,
+                  dp2, dp1, lddp2, lddp1, dxA, dxB, lddxA, lddxB, accA, accB, (int)M, act1, act2, slope1, slope2};
+#define MLPB_CASE(A, B, G)                                                         \
+    if (nta == A && ntb == B && g3 == G) return mlpf::launch_bwd<A, B, G>(a, st);
+    MLPB_CASE(0, 0, 0) MLPB_CASE(1, 0, 0) MLPB_CASE(2, 0, 0) MLPB_CASE(2, 2, 0)
+    MLPB_CASE(0, 0, 1) MLPB_CASE(2, 0, 1) MLPB_CASE(2, 2, 1)
+    MLPB_CASE(0, 0, 4) MLPB_CASE(2, 0, 4) MLPB_CASE(2, 2, 4)
+    MLPB_CASE(0, 0, 8) MLPB_CASE(2, 0, 8) MLPB_CASE(2, 2, 8)
+#undef MLPB_CASE
+    return hipErrorNotSupported;
 }

@@ -252,6 +252,22 @@ int dagnet_op_mlp_chain_fwd(int64_t M, int32_t npieces, const float *const *x, c
                             float slope1, const float *W2, int64_t ldw2, const float *b2, int32_t N2, int32_t act2, float slope2, float *y1,
                             int64_t ldy1, float *y2, int64_t ldy2, const float *Wm, int64_t ldwm, const float *bm, const float *Wl,
                             int64_t ldwl, const float *bl, int32_t Z, float *mu, int64_t ldmu, float *lv, int64_t ldlv, void *stream);
+/* Selects the fused training kernels at run time: bit 0 = dagnet_op_gru_layer_fwd's one-kernel form, bit 1 = dagnet_op_mlp_chain_fwd's,
+ * bit 2 = dagnet_op_mlp2_bwd's (a cleared bit makes the entry point take its layer-by-layer form / return 1); mask < 0 restores
+ * the default (all on, minus DAGNET_NO_GRU_FUSED / DAGNET_NO_MLP_FUSED / DAGNET_NO_MLP_BWD_FUSED).  -> the previous mask.
+ * No counterpart in the reference: a switch for A/B comparisons and tests. */
+int dagnet_op_set_fused(int32_t mask);
+/* Replaces: autograd's backward of such a block (and of its heads) between the gradients that arrive at it - dmu, dlv [M,Z] at the
+ * heads (dy2 = NULL), or dy2 [M,64] at the block output - and the gradients of its input pieces: dp2 = (dmu Wm + dlv Wl | dy2) *
+ * act2'(y2), dp1 = (dp2 W2) * act1'(y1) (both written: the layers' weight gradients are products with them), dxA / dxB (+)= dp1
+ * W1[:, cA : cA + KA] / [:, cB : cB + KB] (NULL: not wanted; acc: add to what is there).  Returns 1 (nothing written) when the
+ * shape has no fused kernel (csrc/mlp_fused.hip: 64 / 64 features, >= 2048 rows, Z in {1, 2, 16, 32}, 16-byte rows). */
+int dagnet_op_mlp2_bwd(int64_t M, const float *dy2, int64_t lddy2, const float *dmu, int64_t lddmu, const float *dlv, int64_t lddlv,
+                       int32_t Z, const float *Wm, int64_t ldwm, const float *Wl, int64_t ldwl, const float *y2, int64_t ldy2,
+                       const float *y1, int64_t ldy1, const float *W2, int64_t ldw2, int32_t act2, float slope2, const float *W1,
+                       int64_t ldw1, int32_t act1, float slope1, float *dp2, int64_t lddp2, float *dp1, int64_t lddp1, float *dxA,
+                       int64_t lddxA, int32_t cA, int32_t KA, int32_t accA, float *dxB, int64_t lddxB, int32_t cB, int32_t KB,
+                       int32_t accB, void *stream);
 /* Replaces: one layer of nn.GRU at seq_len = 1 from its inputs (models/dagnet/model.py:109-110,:186): gi = [x0 | x1] W_ih^T + b_ih,
  * gh = h W_hh^T + b_hh and the gate arithmetic in one call (x1 = NULL, K1 = 0: a single input piece).  gi, gh [M,3R], hn [M,R],
  * gates [M,3R] are contiguous.  rnn_dim 64 with 64-wide pieces and >= 2048 rows runs as ONE kernel (csrc/gru_fused.hip) that

@@ -275,3 +275,50 @@ def test_mlp_chain_matches_torch(M, pieces, gather, Z):
     torch.testing.assert_close(y2.double(), r2, **tol)
     torch.testing.assert_close(mu.double(), r2 @ Wm.double().t() + bm.double(), **tol)
     torch.testing.assert_close(lv.double(), r2 @ Wl.double().t() + bl.double(), **tol)
+
+
+@pytest.mark.parametrize("M,widths,Z,acc", [(4100, (64, 64), 32, (1, 0)), (3000, (64,), 32, (0,)), (2500, (64, 64), 2, (0, 1)), (2300, (), 16, ()),
+                                            (5000, (32,), 0, (0,)), (2600, (), 0, ()), (3000, (64, 64), 16, (1, 1)), (2048, (16,), 0, (1,)),
+                                            (100, (64,), 32, (0,)), (3000, (64,), 8, (0,))])
+def test_mlp2_bwd_matches_torch(M, widths, Z, acc):
+    """dagnet_op_mlp2_bwd: from (dmu, dlv) at the heads (Z > 0) or dy2 at the block output (Z = 0) to dpre2, dpre1 and the input
+    gradients of up to two pieces (overwrite / accumulate), against torch autograd in fp64.  M = 100 and Z = 8 have no fused
+    kernel: the call returns 1 and writes nothing."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(M + sum(widths) + Z)
+    cols, c = [], 5
+    for k in widths:
+        cols.append(c)
+        c += k + 3
+    Ktot = max(c, 8)
+    rnd = lambda *s: torch.randn(s, generator=g).to(DEV)  # noqa: E731
+    W1, W2 = rnd(64, Ktot) / 8, rnd(64, 64) / 8
+    Wm, Wl = rnd(max(Z, 1), 64) / 8, rnd(max(Z, 1), 64) / 8
+    pre1, pre2 = rnd(M, 64), rnd(M, 64)
+    y1, y2 = torch.nn.functional.leaky_relu(pre1, 0.01), torch.nn.functional.leaky_relu(pre2, 0.01)
+    dmu, dlv, dy2 = rnd(M, max(Z, 1)), rnd(M, max(Z, 1)), rnd(M, 64)
+    dx0 = [rnd(M, k) for k in widths]
+    dx = [t.clone() for t in dx0]
+    dp2, dp1 = torch.full((M, 64), float("nan"), device=DEV), torch.full((M, 64), float("nan"), device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    pa = [(None, 0, 0, 0, 0), (None, 0, 0, 0, 0)]
+    for j, k in enumerate(widths):
+        pa[j] = (p(dx[j]), k, cols[j], k, acc[j])
+    heads = Z > 0
+    rc = _ops._lib().dagnet_op_mlp2_bwd(M, None if heads else p(dy2), 64, p(dmu) if heads else None, max(Z, 1), p(dlv) if heads else None, max(Z, 1),
+                                        Z, p(Wm) if heads else None, 64, p(Wl) if heads else None, 64, p(y2), 64, p(y1), 64, p(W2), 64,
+                                        _ops.ACT_LRELU, 0.01, p(W1), Ktot, _ops.ACT_LRELU, 0.01, p(dp2), 64, p(dp1), 64, *pa[0], *pa[1],
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if M < 2048 or Z == 8:
+        assert rc == 1 and torch.isnan(dp2).all() and all(torch.equal(a, b) for a, b in zip(dx, dx0))
+        return
+    assert rc == 0
+    d2 = (dmu.double() @ Wm.double() + dlv.double() @ Wl.double()) if heads else dy2.double()
+    r2 = d2 * torch.where(y2 > 0, 1.0, 0.01).double()
+    r1 = (r2 @ W2.double()) * torch.where(y1 > 0, 1.0, 0.01).double()
+    tol = dict(rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(dp2.double(), r2, **tol)
+    torch.testing.assert_close(dp1.double(), r1, **tol)
+    for j, k in enumerate(widths):
+        want = r1 @ W1[:, cols[j]:cols[j] + k].double() + (dx0[j].double() if acc[j] else 0.0)
+        torch.testing.assert_close(dx[j].double(), want, **tol)

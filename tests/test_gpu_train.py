@@ -230,3 +230,57 @@ def test_side_streams_do_not_change_the_step(kind, kw):
             ref = base_g[k_]
             tol = 1e-4 * float(ref.abs().max()) + 1e-6
             assert float((g[k_] - ref).abs().max()) <= tol, (streams, graphed, k_)
+
+
+@pytest.mark.parametrize("kind,kw", [("dagnet", dict(n_layers=2)), ("avrnn", dict(n_layers=1, z_dim=16)), ("vrnn", dict(n_layers=2))])
+def test_fused_kernels_do_not_change_the_step(kind, kw):
+    """The one-kernel forms of the GRU layer, of the dense blocks and of the blocks' backward (csrc/gru_fused.hip, mlp_fused.hip: taken
+    from 2048 rows up, so the small golden cases above never reach them) against the layer-by-layer forms on the same 2560-row
+    batch: the losses, every gradient and the final hidden state agree to fp32 summation-order noise."""
+    import dagnet_amd
+    from dagnet_amd import _ops, training, synthetic as syn
+    from dagnet_amd.adjacency_matrix import compute_adjs_distsim
+    a = syn.make_args(obs_len=4, pred_len=6, **kw)
+    obs, gt, obs_rel, gt_rel, og, pg, sse = [t.to(DEV) for t in syn.make_batch([10] * 256, 4, 6, 29)]
+    traj, rel = torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0)
+    goals = torch.cat((og, pg), 0).to(torch.int32)
+    eps = syn.uniform_noise(29, "eps", (rel.shape[0] - 1, rel.shape[1], a.z_dim)).to(DEV)
+
+    def run(mask):
+        m = {"vrnn": lambda: dagnet_amd.VRNN(a), "avrnn": lambda: dagnet_amd.AVRNN(a), "dagnet": lambda: dagnet_amd.DAGNet(a, 10)}[kind]()
+        m.load_state_dict(syn.random_state_dict(m, 31))
+        m = m.to(DEV).train()
+        adj = compute_adjs_distsim(a, sse, obs, gt, compact=True) if kind != "vrnn" else None
+        opt = _ops.ClipAdam(list(m.parameters()), lr=1e-3, clip=10.0)
+        training.attach_grad_arena(m, opt)
+        prev = _ops.set_fused(mask)
+        try:
+            opt.zero_grad()
+            if kind == "vrnn":
+                k, n, h = m(rel, eps=eps)
+                c = torch.zeros_like(k)
+            elif kind == "avrnn":
+                k, n, h = m(rel, adj, seq_start_end=sse, eps=eps)
+                c = torch.zeros_like(k)
+            else:
+                k, n, c, h = m(traj, rel, goals, sse, adj, eps=eps)
+            (k + n + 1e-2 * c).backward()
+            _ops.BR.join()
+            torch.cuda.synchronize()
+        finally:
+            assert _ops.set_fused(prev) == mask
+        return [float(v.detach()) for v in (k, n, c)], {k_: p.grad.detach().clone() for k_, p in m.named_parameters()}, h.detach().clone()
+    pl, pg_, ph = run(0)
+    gmax = max(float(v.abs().max()) for v in pg_.values())
+    # mask 6: the dense blocks' kernels only - the same arithmetic in another summation order; mask 7 adds the GRU layer kernel, whose
+    # gates use the hardware exp2 / rcp (1 ulp) instead of expf / tanhf: with random weights the 9-step recurrence through BatchNorm
+    # amplifies that to ~1e-4 in h and ~1e-3 in a few gradients (measured; gradients that are analytically zero - out_att.a, whose
+    # softmax is shift invariant - are noise of magnitude 1e-10 and fall under the absolute term)
+    for mask, rtol in ((6, 1e-4), (7, 3e-3)):
+        fl, fg, fh = run(mask)
+        for x, y in zip(fl, pl):
+            assert abs(x - y) <= 1e-5 * max(1.0, abs(y)), (mask, fl, pl)
+        assert len(fg) > 10
+        for name, ref in pg_.items():
+            assert float((fg[name] - ref).abs().max()) <= rtol * float(ref.abs().max()) + 1e-7 * gmax, (mask, name)
+        torch.testing.assert_close(fh, ph, rtol=10 * rtol, atol=10 * rtol)

@@ -326,9 +326,12 @@ __global__ __launch_bounds__(256) void col_reduce4_kernel(int64_t M, int N, int 
     const int64_t m0 = (int64_t)blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
     float4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
     if (c < N) {
+        // N need not be a multiple of 4 (g_dim = 90 in rows of 92): the columns of a straddling quad past N read the row padding
+        // into sums of their own that are never written; the statistics are fetched element by element
         float4 mu = {0.f, 0.f, 0.f, 0.f}, is = {0.f, 0.f, 0.f, 0.f};
-        if (MODE >= 1) mu = *reinterpret_cast<const float4 *>(stat + c);
-        if (MODE == 2) is = *reinterpret_cast<const float4 *>(stat + N + c);
+        if (MODE >= 1) mu = make_float4(stat[c], c + 1 < N ? stat[c + 1] : 0.f, c + 2 < N ? stat[c + 2] : 0.f, c + 3 < N ? stat[c + 3] : 0.f);
+        if (MODE == 2)
+            is = make_float4(stat[N + c], c + 1 < N ? stat[N + c + 1] : 0.f, c + 2 < N ? stat[N + c + 2] : 0.f, c + 3 < N ? stat[N + c + 3] : 0.f);
 #pragma unroll 4
         for (int64_t m = m0 + rl; m < m1; m += 16) {
             const float4 x = *reinterpret_cast<const float4 *>(X + m * ldx + c);
@@ -921,8 +924,10 @@ static hipError_t col_reduce(int64_t M, int N, const float *X, int64_t ldx, cons
                              int accumulate, hipStream_t st) {
     const int splits = col_splits(M);
     const int rows = (int)((M + splits - 1) / splits);
-    auto al = [](const float *q, int64_t ld) { return !q || (((reinterpret_cast<uintptr_t>(q) & 15) == 0) && (ld & 3) == 0); };
-    if ((N & 3) == 0 && al(X, ldx) && al(stat, 0) && (MODE < 2 || (al(dOut, ldd) && (!tanh_out || al(Out, ldo)))))
+    // 16-byte rows: aligned base, row stride a multiple of 4 that covers the last quad (N itself may be 90)
+    const int64_t n4 = (N + 3) & ~3;
+    auto al = [n4](const float *q, int64_t ld) { return !q || (((reinterpret_cast<uintptr_t>(q) & 15) == 0) && (ld & 3) == 0 && ld >= n4); };
+    if (al(X, ldx) && (MODE < 2 || (al(dOut, ldd) && (!tanh_out || al(Out, ldo)))))
         hipLaunchKernelGGL((tops::col_reduce4_kernel<MODE>), dim3((N + 63) / 64, splits), dim3(256), 0, st, M, N, rows, X, ldx, stat, dOut,
                            ldd, Out, ldo, tanh_out, part);
     else

@@ -276,7 +276,7 @@ extern "C" hipError_t dn_gemm_skinny(const float *A, int64_t lda, const float *B
     // (n-tiles, k-groups, workgroups per CU the registers allow: accumulators + two A tiles; 2 with the table term)
     SK_CASE(1, 4, 4) SK_CASE(1, 8, 4) SK_CASE(1, 12, 4)
     SK_CASE(2, 4, 4) SK_CASE(2, 8, 4) SK_CASE(2, 12, 3)
-    SK_CASE(3, 4, 4) SK_CASE(3, 8, 3) SK_CASE(3, 12, 2)
+    SK_CASE(3, 4, 4) SK_CASE(3, 8, 3) SK_CASE(3, 12, 3)
     SK_CASE(6, 4, 3) SK_CASE(6, 8, 2) SK_CASE(6, 12, 2)
 #undef SK_CASE
     return hipErrorNotSupported;

@@ -365,14 +365,109 @@ __global__ __launch_bounds__(256) void col_reduce4_kernel(int64_t M, int N, int 
     }
 }
 
+// BatchNorm forward statistics in ONE pass over X (mean and sum of squared deviations), for 16-byte rows: part[split] = [mean_s | M2_s]
+// of the split's rows.  A thread sums (x - K) and (x - K)^2 with K = its own first value (deviations of the size of the spread: no
+// E[x^2] - mean^2 cancellation), turns them into (mean, M2) and the 16 row lanes merge pairwise with the parallel-variance formula
+// M2 = M2_a + M2_b + d^2 n_a n_b / n; bn_finish_stat_kernel merges the splits in fp64.  (Two passes + three small launches before.)
+__global__ __launch_bounds__(256) void bn_moments_kernel(int64_t M, int N, int rows_per_split, const float *__restrict__ X, int64_t ldx,
+                                                         float *__restrict__ part) {
+    __shared__ float smean[16][64 + 4], sm2[16][64 + 4], scnt[16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 64 + cl * 4;
+    const int64_t m0 = (int64_t)blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
+    float4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f}, k = {0.f, 0.f, 0.f, 0.f};
+    int cnt = 0;
+    if (c < N && m0 + rl < m1) {
+        k = *reinterpret_cast<const float4 *>(X + (m0 + rl) * ldx + c);
+#pragma unroll 4
+        for (int64_t m = m0 + rl; m < m1; m += 16) {
+            const float4 x = *reinterpret_cast<const float4 *>(X + m * ldx + c);
+            const float d0 = x.x - k.x, d1 = x.y - k.y, d2 = x.z - k.z, d3 = x.w - k.w;
+            s1.x += d0; s1.y += d1; s1.z += d2; s1.w += d3;
+            s2.x += d0 * d0; s2.y += d1 * d1; s2.z += d2 * d2; s2.w += d3 * d3;
+            ++cnt;
+        }
+    }
+    const float inv = cnt ? 1.0f / (float)cnt : 0.f;
+    const float4 mean = {k.x + s1.x * inv, k.y + s1.y * inv, k.z + s1.z * inv, k.w + s1.w * inv};
+    const float4 m2 = {s2.x - s1.x * s1.x * inv, s2.y - s1.y * s1.y * inv, s2.z - s1.z * s1.z * inv, s2.w - s1.w * s1.w * inv};
+    *reinterpret_cast<float4 *>(&smean[rl][cl * 4]) = mean;
+    *reinterpret_cast<float4 *>(&sm2[rl][cl * 4]) = m2;
+    if (cl == 0) scnt[rl] = (float)cnt;          // the same for all columns of a row lane
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x, col = blockIdx.x * 64 + l;
+        if (col < N) {
+            float n = scnt[0], mu = smean[0][l], q = sm2[0][l];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) {
+                const float nb = scnt[r];
+                if (nb > 0.f) {
+                    const float nn = n + nb, d = smean[r][l] - mu;
+                    mu += d * (nb / nn);
+                    q += sm2[r][l] + d * d * (n * nb / nn);
+                    n = nn;
+                }
+            }
+            part[((int64_t)blockIdx.y * 2 + 0) * N + col] = mu;
+            part[((int64_t)blockIdx.y * 2 + 1) * N + col] = q;
+        }
+    }
+}
+
+// merge of the splits' (mean, M2) in fp64 and everything bn_stat_kernel does: stat = [mean | invstd], running statistics
+__global__ __launch_bounds__(256) void bn_finish_stat_kernel(int N, int64_t M, int splits, int rows_per_split, const float *__restrict__ part,
+                                                             float eps, float momentum, float *__restrict__ stat,
+                                                             float *__restrict__ run_mean, float *__restrict__ run_var) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= N) return;
+    double n = 0.0, mu = 0.0, q = 0.0;
+    for (int k = lane; k < splits; k += 64) {
+        const int64_t m0 = (int64_t)k * rows_per_split;
+        const double nb = (double)(min(M, m0 + rows_per_split) - m0);
+        if (nb <= 0.0) continue;
+        const double mb = part[((int64_t)k * 2 + 0) * N + c], qb = part[((int64_t)k * 2 + 1) * N + c];
+        const double nn = n + nb, d = mb - mu;
+        mu += d * (nb / nn);
+        q += qb + d * d * (n * nb / nn);
+        n = nn;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double nb = __shfl_xor(n, o), mb = __shfl_xor(mu, o), qb = __shfl_xor(q, o);
+        const double nn = n + nb;
+        if (nn > 0.0) {
+            const double d = mb - mu;
+            // symmetric form: both partners of an exchange arrive at the same triple
+            mu = (n * mu + nb * mb) / nn;
+            q = q + qb + d * d * (n * nb / nn);
+        }
+        n = nn;
+    }
+    if (lane == 0) {
+        const float mean = (float)mu, var_sum = (float)q;
+        const float var = var_sum / (float)M;
+        stat[c] = mean;
+        stat[N + c] = 1.0f / sqrtf(var + eps);
+        if (run_mean) {
+            run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
+            const float unb = M > 1 ? var_sum / (float)(M - 1) : var;
+            run_var[c] = (1.0f - momentum) * run_var[c] + momentum * unb;
+        }
+    }
+}
+
 // stage 2: out_q[c] (+)= scale * sum_split part[split][q][c]; one wave per column, lanes stride over the splits
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+// extra0 / extra1 (nullable): the two sums are also added into (or stored to) a second pair of vectors - the BatchNorm backward's
+// dbeta / dgamma, which were two copy launches of their own
 __global__ __launch_bounds__(256) void col_finish_kernel(int N, int splits, const float *__restrict__ part, float scale,
-                                                         float *__restrict__ out0, float *__restrict__ out1, int accumulate) {
+                                                         float *__restrict__ out0, float *__restrict__ out1, int accumulate,
+                                                         float *__restrict__ extra0, float *__restrict__ extra1, int extra_accumulate) {
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= N) return;
     double s0 = 0.0, s1 = 0.0;
@@ -385,6 +480,8 @@ __global__ __launch_bounds__(256) void col_finish_kernel(int N, int splits, cons
     if (lane == 0) {
         if (out0) out0[c] = (accumulate ? out0[c] : 0.f) + (float)(s0 * scale);
         if (out1) out1[c] = (accumulate ? out1[c] : 0.f) + (float)(s1 * scale);
+        if (extra0) extra0[c] = (extra_accumulate ? extra0[c] : 0.f) + (float)(s0 * scale);
+        if (extra1) extra1[c] = (extra_accumulate ? extra1[c] : 0.f) + (float)(s1 * scale);
     }
 }
 
@@ -921,7 +1018,7 @@ extern "C" int64_t dn_t_col_workspace(int64_t M, int N) { return (int64_t)col_sp
 template <int MODE>
 static hipError_t col_reduce(int64_t M, int N, const float *X, int64_t ldx, const float *stat, const float *dOut, int64_t ldd,
                              const float *Out, int64_t ldo, int tanh_out, float *part, float scale, float *out0, float *out1,
-                             int accumulate, hipStream_t st) {
+                             int accumulate, hipStream_t st, float *extra0 = nullptr, float *extra1 = nullptr, int extra_accumulate = 0) {
     const int splits = col_splits(M);
     const int rows = (int)((M + splits - 1) / splits);
     // 16-byte rows: aligned base, row stride a multiple of 4 that covers the last quad (N itself may be 90)
@@ -933,7 +1030,8 @@ static hipError_t col_reduce(int64_t M, int N, const float *X, int64_t ldx, cons
     else
         hipLaunchKernelGGL((tops::col_reduce_kernel<MODE>), dim3((N + 63) / 64, splits), dim3(256), 0, st, M, N, rows, X, ldx, stat, dOut,
                            ldd, Out, ldo, tanh_out, part);
-    hipLaunchKernelGGL(tops::col_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, splits, part, scale, out0, out1, accumulate);
+    hipLaunchKernelGGL(tops::col_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, splits, part, scale, out0, out1, accumulate, extra0,
+                       extra1, extra_accumulate);
     return hipGetLastError();
 }
 
@@ -988,6 +1086,15 @@ extern "C" hipError_t dn_t_bn_fwd(int64_t M, int N, const float *X, int64_t ldx,
                                   float momentum, int tanh_out, float *Y, int64_t ldy, float *stat, float *run_mean, float *run_var,
                                   float *tmp, float *part, hipStream_t st) {
     if (M == 0 || N == 0) return hipSuccess;
+    if (((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ldx & 3) == 0 && ldx >= ((N + 3) & ~3)) {      // 16-byte rows: one pass
+        const int splits = col_splits(M);
+        const int rows = (int)((M + splits - 1) / splits);
+        hipLaunchKernelGGL(tops::bn_moments_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, st, M, N, rows, X, ldx, part);
+        hipLaunchKernelGGL(tops::bn_finish_stat_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, M, splits, rows, part, eps, momentum, stat,
+                           run_mean, run_var);
+        hipLaunchKernelGGL(tops::bn_apply_kernel, T_GRID(M * N), 0, st, M, N, X, ldx, stat, gamma, beta, tanh_out, Y, ldy);
+        return hipGetLastError();
+    }
     hipError_t e = col_reduce<0>(M, N, X, ldx, nullptr, nullptr, 0, nullptr, 0, 0, part, 1.0f / (float)M, tmp, nullptr, 0, st);
     if (e != hipSuccess) return e;
     e = col_reduce<1>(M, N, X, ldx, tmp, nullptr, 0, nullptr, 0, 0, part, 1.0f, tmp + N, nullptr, 0, st);
@@ -1002,12 +1109,10 @@ extern "C" hipError_t dn_t_bn_bwd(int64_t M, int N, const float *X, int64_t ldx,
                                   int64_t ldd, const float *Out, int64_t ldo, int tanh_out, float *dX, int64_t ldg, float *dgamma,
                                   float *dbeta, int accumulate, float *sums, float *part, hipStream_t st) {
     if (M == 0 || N == 0) return hipSuccess;
-    hipError_t e = col_reduce<2>(M, N, X, ldx, stat, dOut, ldd, Out, ldo, tanh_out, part, 1.0f, sums, sums + N, 0, st);
+    hipError_t e = col_reduce<2>(M, N, X, ldx, stat, dOut, ldd, Out, ldo, tanh_out, part, 1.0f, sums, sums + N, 0, st, dbeta, dgamma, accumulate);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(tops::bn_bwd_kernel, T_GRID(M * N), 0, st, M, N, X, ldx, stat, gamma, dOut, ldd, Out, ldo, tanh_out, sums, dX, ldg);
-    e = dn_t_copy2d(1, N, sums, N, dbeta, N, accumulate, st);
-    if (e != hipSuccess) return e;
-    return dn_t_copy2d(1, N, sums + N, N, dgamma, N, accumulate, st);
+    return hipGetLastError();
 }
 
 extern "C" int64_t dn_t_gat_lds_bytes(int n_max, int F, int backward) {

@@ -22,7 +22,7 @@ ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
 OP_EXPORTS = (
     "dagnet_op_gemm", "dagnet_op_gemm_dact", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
-    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_mlp_chain_fwd", "dagnet_op_mlp2_bwd", "dagnet_op_set_fused", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
+    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_mlp_chain_fwd", "dagnet_op_mlp2_bwd", "dagnet_op_linear_pieces_bwd", "dagnet_op_set_fused", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
     "dagnet_op_gat_attn_fwd", "dagnet_op_gat_attn_bwd", "dagnet_op_adj_matmul", "dagnet_op_disposition", "dagnet_op_sumsq",
@@ -59,6 +59,7 @@ def _lib():
         f32 = C.c_float
         lib.dagnet_op_mlp2_bwd.argtypes = [i64, vp, i64, vp, i64, vp, i64, i32, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, f32, vp, i64, i32, f32,
                                            vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, i32, i32, vp]
+        lib.dagnet_op_linear_pieces_bwd.argtypes = [i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, vp, i64, i32, i32, i32, vp]
         lib.dagnet_op_gru_pack.argtypes = [i32, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]
         lib.dagnet_op_gru_pack_floats.argtypes = [i32, i32, i32]
         lib.dagnet_op_gru_pack_floats.restype = i64
@@ -589,6 +590,11 @@ class MlpChainFn(torch.autograd.Function):
         ctx.n_in = 12 + n
         ctx.has = (y2 is not None, heads is not None)
         ctx.set_materialize_grads(False)
+        if y2 is None and act[0] == ACT_NONE and gidx is None:      # one Linear without activation: its pieces' gradients in one kernel
+            ctx.slot = POOL.site()
+            ctx.one = (l1, tuple(cols))
+            ctx.xs = xs
+            ctx.gaccs = [_gacc_of(x) for x in xs]
         if y2 is not None:               # what the one-kernel backward needs (the unfused one keeps its own records in the lazy nodes)
             ctx.slot = POOL.site()
             ctx.blk = (l1, l2, heads, act, slope, tuple(cols), gidx, gcol, mu.shape[1] if heads is not None else 0)
@@ -605,10 +611,51 @@ class MlpChainFn(torch.autograd.Function):
         out = [None] * ctx.n_in
         if two and MlpChainFn._fused_backward(ctx, g, out):
             return tuple(out)
+        if not two and getattr(ctx, "one", None) is not None and MlpChainFn._fused_backward_one(ctx, g[0], out):
+            return tuple(out)
         out[1 if two else 0] = g[0]
         if heads:
             out[2], out[3] = g[1], g[2]
         return tuple(out)
+
+    @staticmethod
+    def _fused_backward_one(ctx, dy, out):
+        """Single Linear without activation over its pieces: both input gradients from one pass over dy (dagnet_op_linear_pieces_bwd);
+        the weight gradient is recorded as LinearFn.backward records it (dpre = dy)."""
+        (W, b), cols = ctx.one
+        xs = ctx.xs
+        if dy is None or _sink(W) is None or _defer(W) is None or (b is not None and _sink(b) is None):
+            return False
+        want = [i for i in range(len(xs)) if ctx.needs_input_grad[12 + i]]
+        if not 1 <= len(want) <= 2 or any(xs[i].shape[1] % 4 or xs[i].shape[1] > 64 for i in want):
+            return False
+        dy = _rows(dy)
+        M = dy.shape[0]
+        dst = []
+        for i in want:
+            gacc = ctx.gaccs[i]
+            if gacc is not None:
+                dst.append((gacc.buffer(xs[i]), int(gacc.started), gacc))
+            else:
+                dst.append((POOL.at(ctx.slot, "dx%d" % i, tuple(xs[i].shape), dy), 0, None))
+        pa = [(None, 0, 0, 0, 0), (None, 0, 0, 0, 0)]
+        for j, i in enumerate(want):
+            (ptr, ld) = _m(dst[j][0], "dx")
+            pa[j] = (ptr, ld, int(cols[i]), xs[i].shape[1], dst[j][1])
+        (pd, ldd), (w, ldw) = _m(dy, "dy"), _m(W, "W")
+        rc = _lib().dagnet_op_linear_pieces_bwd(M, pd, ldd, w, ldw, *pa[0], *pa[1], _stream(dy.device))
+        if rc == 1:
+            return False
+        _check(rc)
+        for j, i in enumerate(want):
+            if dst[j][2] is not None:
+                dst[j][2].done()
+            else:
+                out[12 + i] = dst[j][0]
+        sink, bs = _sink(W), (_sink(b) if b is not None else None)
+        for s_, (x, c0) in enumerate(zip(xs, cols)):
+            _defer(W).add((id(W), c0), dy, x, sink[:, c0:c0 + x.shape[1]], bias_dst=bs if s_ == 0 else None)
+        return True
 
     @staticmethod
     def _fused_backward(ctx, g, out):

@@ -1790,6 +1790,21 @@ extern "C" int dagnet_op_mlp2_bwd(int64_t M, const float *dy2, int64_t lddy2, co
     HIP_TRY(e);
     return DAGNET_OK;
 }
+extern "C" hipError_t dn_linear_pieces_bwd_fused(int64_t M, const float *dy, int64_t lddy, const float *W, int64_t ldw, float *dxA,
+                                                 int64_t lddxA, int cA, int KA, int accA, float *dxB, int64_t lddxB, int cB, int KB, int accB,
+                                                 hipStream_t st);
+// Input gradients of one Linear (64 outputs, no activation) over two input pieces from one pass over dy.  -> DAGNET_OK, or 1 when
+// the shape has no fused kernel (nothing written).
+extern "C" int dagnet_op_linear_pieces_bwd(int64_t M, const float *dy, int64_t lddy, const float *W, int64_t ldw, float *dxA, int64_t lddxA,
+                                           int32_t cA, int32_t KA, int32_t accA, float *dxB, int64_t lddxB, int32_t cB, int32_t KB,
+                                           int32_t accB, void *stream) {
+    OP_NEED(M >= 0, "bad argument");
+    if (!(fused_mask() & 4) || M == 0) return 1;
+    const hipError_t e = dn_linear_pieces_bwd_fused(M, dy, lddy, W, ldw, dxA, lddxA, cA, KA, accA, dxB, lddxB, cB, KB, accB, OP_ST);
+    if (e == hipErrorNotSupported) return 1;
+    HIP_TRY(e);
+    return DAGNET_OK;
+}
 extern "C" int dagnet_op_gru_bwd(int64_t M, int32_t R, const float *dhn, const float *gates, const float *gh, const float *h, float *dgi,
                                  float *dgh, float *dh, void *stream) {
     OP_NEED(M >= 0 && R >= 1 && (M == 0 || (dhn && gates && gh && h && dgi && dgh && dh)), "bad argument");

@@ -581,3 +581,100 @@ extern "C" hipError_t dn_mlp2_bwd_fused(int64_t M, const float *dy2, int64_t ldd
 #undef MLPB_CASE
     return hipErrorNotSupported;
 }
+
+// Input gradients of ONE linear layer over two input pieces (lg_hiddens / lg: [graph output | h] -> 64, no activation):
+// dxA (+)= dy W[:, cA : cA + KA], dxB (+)= dy W[:, cB : cB + KB] from one pass over dy (two products, each reading dy, before).
+namespace mlpf {
+
+struct PArgs {
+    const float *dy; int64_t lddy;                         // [M, 64]
+    const float *W; int64_t ldw; int cA, cB, KA, KB;       // [64, Ktot]
+    float *dxA, *dxB; int64_t lddxA, lddxB; int accA, accB;
+    int M;
+};
+
+template <int NTA, int NTB>
+__global__ __launch_bounds__(256, 4) void linear_pieces_bwd_kernel(const PArgs p) {
+    extern __shared__ float lds[];           // wAt [NTA][8][64][4] | wBt [NTB][8][64][4]
+    float *wAt = lds, *wBt = wAt + NTA * 8 * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    for (int e = tid; e < NTA * 8 * 256; e += 256) {
+        const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 7, nt = e >> 11, n = nt * 32 + (l & 31);
+        wAt[e] = n < p.KA ? p.W[(int64_t)(8 * g + 4 * (l >> 5) + i) * p.ldw + p.cA + n] : 0.f;
+    }
+    for (int e = tid; e < NTB * 8 * 256; e += 256) {
+        const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 7, nt = e >> 11, n = nt * 32 + (l & 31);
+        wBt[e] = n < p.KB ? p.W[(int64_t)(8 * g + 4 * (l >> 5) + i) * p.ldw + p.cB + n] : 0.f;
+    }
+    __syncthreads();
+    const int n_tiles = (p.M + 31) >> 5;
+    const int stride = (int)gridDim.x * 4;
+    const i32x4 rdy = make_rsrc(p.dy, (int64_t)p.M * p.lddy * 4);
+    const i32x4 rxa = make_rsrc(p.dxA, (int64_t)p.M * p.lddxA * 4);
+    const i32x4 rxb = make_rsrc(NTB ? p.dxB : p.dxA, (int64_t)p.M * (NTB ? p.lddxB : p.lddxA) * 4);
+    for (int tile = (int)blockIdx.x * 4 + wave; tile < n_tiles; tile += stride) {
+        const int row = tile * 32 + lr;
+        f32x4 pq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pq[q] = mf_load4(rdy, row * (int)p.lddy * 4 + 16 * lh + q * 32, 0, 0);
+        auto piece = [&](auto nt_tag, const float *wt, const i32x4 rx, const int ldx4, const int K, const int accum) {
+            constexpr int NTP = decltype(nt_tag)::value;
+            f32x16 ax[NTP ? NTP : 1];
+#pragma unroll
+            for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    if (accum && nt * 32 + 8 * a + 4 * lh < K) c = mf_load4(rx, row * ldx4 + (nt * 32 + 8 * a + 4 * lh) * 4, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ax[nt][4 * a + i] = c[i];
+                }
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+#pragma unroll
+                for (int nt = 0; nt < NTP; ++nt) {
+                    const f32x4 w = *reinterpret_cast<const f32x4 *>(wt + ((nt * 8 + g) * 64 + lane) * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ax[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[i], pq[g][i], ax[nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NTP; ++nt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int f0 = nt * 32 + 8 * a + 4 * lh;
+                    if (f0 < K) mf_store4(f32x4{ax[nt][4 * a], ax[nt][4 * a + 1], ax[nt][4 * a + 2], ax[nt][4 * a + 3]}, rx, row * ldx4 + f0 * 4, 0, 0);
+                }
+        };
+        piece(std::integral_constant<int, NTA>{}, wAt, rxa, (int)p.lddxA * 4, p.KA, p.accA);
+        if constexpr (NTB > 0) piece(std::integral_constant<int, NTB>{}, wBt, rxb, (int)p.lddxB * 4, p.KB, p.accB);
+    }
+}
+
+}  // namespace mlpf
+
+// -> hipErrorNotSupported (nothing written) unless: 64 output features, >= 2048 rows, piece widths multiples of 4 up to 64, 16-byte rows.
+extern "C" hipError_t dn_linear_pieces_bwd_fused(int64_t M, const float *dy, int64_t lddy, const float *W, int64_t ldw, float *dxA,
+                                                 int64_t lddxA, int cA, int KA, int accA, float *dxB, int64_t lddxB, int cB, int KB, int accB,
+                                                 hipStream_t st) {
+    if (M < 2048 || !dy || !W || !dxA) return hipErrorNotSupported;
+    if ((lddy & 3) || lddy < 64 || (reinterpret_cast<uintptr_t>(dy) & 15) || M * lddy * 4 >= 0x7fffffffLL) return hipErrorNotSupported;
+    auto okp = [&](const float *q, int64_t ld, int K) {
+        return !(K & 3) && K >= 4 && K <= 64 && !(ld & 3) && ld >= K && !(reinterpret_cast<uintptr_t>(q) & 15) && M * ld * 4 < 0x7fffffffLL;
+    };
+    if (!okp(dxA, lddxA, KA) || (dxB && !okp(dxB, lddxB, KB))) return hipErrorNotSupported;
+    const int nta = (KA + 31) / 32, ntb = dxB ? (KB + 31) / 32 : 0;
+    mlpf::PArgs a{dy, lddy, W, ldw, cA, cB, KA, KB, dxA, dxB, lddxA, lddxB, accA, accB, (int)M};
+    const int64_t tiles = (M + 31) / 32;
+    const int64_t blocks = std::min<int64_t>((tiles + 3) / 4, 256 * 4);
+    const size_t lds = (size_t)(nta + ntb) * 8 * 256 * sizeof(float);
+#define LPB_CASE(A, B)                                                                                                        \
+    if (nta == A && ntb == B) {                                                                                               \
+        hipLaunchKernelGGL((mlpf::linear_pieces_bwd_kernel<A, B>), dim3((unsigned)blocks), dim3(256), lds, st, a);            \
+        return hipGetLastError();                                                                                             \
+    }
+    LPB_CASE(2, 2) LPB_CASE(2, 0) LPB_CASE(1, 0) LPB_CASE(2, 1) LPB_CASE(1, 2) LPB_CASE(1, 1)
+#undef LPB_CASE
+    return hipErrorNotSupported;
+}

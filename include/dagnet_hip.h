@@ -252,6 +252,13 @@ int dagnet_op_mlp_chain_fwd(int64_t M, int32_t npieces, const float *const *x, c
                             float slope1, const float *W2, int64_t ldw2, const float *b2, int32_t N2, int32_t act2, float slope2, float *y1,
                             int64_t ldy1, float *y2, int64_t ldy2, const float *Wm, int64_t ldwm, const float *bm, const float *Wl,
                             int64_t ldwl, const float *bl, int32_t Z, float *mu, int64_t ldmu, float *lv, int64_t ldlv, void *stream);
+/* Replaces: autograd's input gradients of lg_hiddens / lg (a Linear with 64 outputs and no activation over [graph output | h],
+ * models/dagnet/model.py:96,190): dxA (+)= dy W[:, cA : cA + KA], dxB (+)= dy W[:, cB : cB + KB] (dxB NULL: one piece) from one pass
+ * over dy [M,64].  Returns 1 (nothing written) when the shape has no fused kernel (>= 2048 rows, widths multiples of 4 up to 64,
+ * 16-byte rows); switched by bit 2 of dagnet_op_set_fused. */
+int dagnet_op_linear_pieces_bwd(int64_t M, const float *dy, int64_t lddy, const float *W, int64_t ldw, float *dxA, int64_t lddxA,
+                                int32_t cA, int32_t KA, int32_t accA, float *dxB, int64_t lddxB, int32_t cB, int32_t KB, int32_t accB,
+                                void *stream);
 /* Selects the fused training kernels at run time: bit 0 = dagnet_op_gru_layer_fwd's one-kernel form, bit 1 = dagnet_op_mlp_chain_fwd's,
  * bit 2 = dagnet_op_mlp2_bwd's (a cleared bit makes the entry point take its layer-by-layer form / return 1); mask < 0 restores
  * the default (all on, minus DAGNET_NO_GRU_FUSED / DAGNET_NO_MLP_FUSED / DAGNET_NO_MLP_BWD_FUSED).  -> the previous mask.

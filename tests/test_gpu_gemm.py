@@ -322,3 +322,32 @@ def test_mlp2_bwd_matches_torch(M, widths, Z, acc):
     for j, k in enumerate(widths):
         want = r1 @ W1[:, cols[j]:cols[j] + k].double() + (dx0[j].double() if acc[j] else 0.0)
         torch.testing.assert_close(dx[j].double(), want, **tol)
+
+
+@pytest.mark.parametrize("M,widths,acc", [(4100, (64, 64), (1, 0)), (2500, (64,), (0,)), (3000, (32, 64), (0, 1)), (2048, (64, 16), (1, 1)),
+                                          (100, (64, 64), (0, 0))])
+def test_linear_pieces_bwd_matches_torch(M, widths, acc):
+    """dagnet_op_linear_pieces_bwd: dx_s (+)= dy W[:, c_s : c_s + K_s] for two pieces from one pass over dy, against fp64 torch;
+    M = 100 has no fused kernel (returns 1, writes nothing)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(M + sum(widths))
+    cols, c = [], 3
+    for k in widths:
+        cols.append(c)
+        c += k + 5
+    rnd = lambda *s: torch.randn(s, generator=g).to(DEV)  # noqa: E731
+    W, dy = rnd(64, c) / 8, rnd(M, 64)
+    dx0 = [rnd(M, k) for k in widths]
+    dx = [t.clone() for t in dx0]
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    pa = [(None, 0, 0, 0, 0), (None, 0, 0, 0, 0)]
+    for j, k in enumerate(widths):
+        pa[j] = (p(dx[j]), k, cols[j], k, acc[j])
+    rc = _ops._lib().dagnet_op_linear_pieces_bwd(M, p(dy), 64, p(W), c, *pa[0], *pa[1], C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if M < 2048:
+        assert rc == 1 and all(torch.equal(a, b) for a, b in zip(dx, dx0))
+        return
+    assert rc == 0
+    for j, k in enumerate(widths):
+        want = dy.double() @ W[:, cols[j]:cols[j] + k].double() + (dx0[j].double() if acc[j] else 0.0)
+        torch.testing.assert_close(dx[j].double(), want, rtol=2e-5, atol=2e-5)

@@ -590,12 +590,12 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_fwd_kernel(Scenes sc, const fl
     extern __shared__ __align__(16) float sm[];
     const int s = blockIdx.x, hd = blockIdx.y;
     const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, FP = (F + 3) & ~3, F4 = FP >> 2;
-    float *wh = sm, *s1 = wh + n * FP, *s2 = s1 + n, *att = s2 + n;
-    const float *ah = a + (int64_t)hd * 2 * F;
+    float *wh = sm, *s1 = wh + n * FP, *s2 = s1 + n, *att = s2 + n, *ah = att + n * n;
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
     const FastDiv dFP(FP), dF4(F4);
+    for (int e = tid; e < 2 * F; e += GAT_T) ah[e] = a[(int64_t)hd * 2 * F + e];      // the attention vector: read F times per row below
     for (int e = tid; e < n * FP; e += GAT_T) {
         const int i = dFP(e), f = e - i * FP;
         wh[e] = f < F ? Wh[(int64_t)(b + i) * ldw + hd * F + f] : 0.f;
@@ -635,12 +635,12 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
     const int s = blockIdx.x, hd = blockIdx.y;
     const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, FP = (F + 3) & ~3, F4 = FP >> 2;
     float *wh = sm, *dO = wh + n * FP, *s1 = dO + n * FP, *s2 = s1 + n, *ds1 = s2 + n, *ds2 = ds1 + n, *dot = ds2 + n;
-    float *att = dot + n, *dpre = att + n * n;
-    const float *ah = a + (int64_t)hd * 2 * F;
+    float *att = dot + n, *dpre = att + n * n, *ah = dpre + n * n;
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
     const FastDiv dFP(FP), dF4(F4), dn(n);
+    for (int e = tid; e < 2 * F; e += GAT_T) ah[e] = a[(int64_t)hd * 2 * F + e];
     for (int e = tid; e < n * FP; e += GAT_T) {
         const int ii = dFP(e), f = e - ii * FP;
         float w = 0.f, g = 0.f;
@@ -758,17 +758,18 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_fwd_heads_kernel(Scenes sc, co
     extern __shared__ float sm[];
     const int s = blockIdx.x;
     const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, HF = H * F, nn = n * n;
-    float *wh = sm, *s1 = wh + n * HF, *s2 = s1 + H * n, *att = s2 + H * n;
+    float *wh = sm, *s1 = wh + n * HF, *s2 = s1 + H * n, *att = s2 + H * n, *as = att + H * nn;
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
     const FastDiv dHF(HF), dF(F);
+    for (int e = tid; e < H * 2 * F; e += GAT_T) as[e] = a[e];          // the heads' attention vectors
     for (int e = tid; e < n * HF; e += GAT_T) {
         const int i = dHF(e);
         wh[e] = Wh[(int64_t)(b + i) * ldw + (e - i * HF)];
     }
     __syncthreads();
-    gat_logits_heads(n, H, F, rld, wh, a, ablk, alpha, s1, s2, att, tid);
+    gat_logits_heads(n, H, F, rld, wh, as, ablk, alpha, s1, s2, att, tid);
     for (int e = tid; e < n * HF; e += GAT_T) {
         const int i = dHF(e), c = e - i * HF, hd = dF(c);
         const float *arow = att + hd * nn + i * n;
@@ -789,11 +790,12 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_heads_kernel(Scenes sc, co
     const int s = blockIdx.x;
     const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, HF = H * F, nn = n * n, Hn = H * n;
     float *wh = sm, *dO = wh + n * HF, *s1 = dO + n * HF, *s2 = s1 + Hn, *ds1 = s2 + Hn, *ds2 = ds1 + Hn, *dot = ds2 + Hn;
-    float *att = dot + Hn, *dpre = att + H * nn;
+    float *att = dot + Hn, *dpre = att + H * nn, *as = dpre + H * nn;
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
     const FastDiv dHF(HF), dF(F), dnn(nn), dn(n), d2F(2 * F);
+    for (int e = tid; e < H * 2 * F; e += GAT_T) as[e] = a[e];
     for (int e = tid; e < n * HF; e += GAT_T) {
         const int i = dHF(e), c = e - i * HF;
         const int64_t row = b + i;
@@ -803,7 +805,7 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_heads_kernel(Scenes sc, co
         dO[e] = g;
     }
     __syncthreads();
-    gat_logits_heads(n, H, F, rld, wh, a, ablk, alpha, s1, s2, att, tid);
+    gat_logits_heads(n, H, F, rld, wh, as, ablk, alpha, s1, s2, att, tid);
     // d att_ij = dO_i . Wh_j (per head)
     for (int e = tid; e < H * nn; e += GAT_T) {
         const int hd = dnn(e), ij = e - hd * nn, i = dn(ij), j = ij - i * n;
@@ -834,7 +836,7 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_heads_kernel(Scenes sc, co
     __syncthreads();
     for (int e = tid; e < n * HF; e += GAT_T) {
         const int j = dHF(e), c = e - j * HF, hd = dF(c), f = c - hd * F;
-        const float *ah = a + (int64_t)hd * 2 * F;
+        const float *ah = as + hd * 2 * F;
         float acc = ds1[hd * n + j] * ah[f] + ds2[hd * n + j] * ah[F + f];
         const float *ap = att + hd * nn;
         for (int i = 0; i < n; ++i) acc += ap[i * n + j] * dO[i * HF + c];
@@ -1117,7 +1119,7 @@ extern "C" hipError_t dn_t_bn_bwd(int64_t M, int N, const float *X, int64_t ldx,
 
 extern "C" int64_t dn_t_gat_lds_bytes(int n_max, int F, int backward) {
     const int64_t n = n_max, FP = (F + 3) & ~3;          // rows of Wh / dO are padded to float4s in LDS
-    return sizeof(float) * (backward ? 2 * n * FP + 5 * n + 2 * n * n : n * FP + 2 * n + n * n);
+    return sizeof(float) * ((backward ? 2 * n * FP + 5 * n + 2 * n * n : n * FP + 2 * n + n * n) + 2 * FP);     // + the head's attention vector
 }
 extern "C" hipError_t dn_t_gat_attn_fwd(const int32_t *scene_ptr, const int64_t *off_compact, int S, int n_max, int64_t adj_ld, const float *adj,
                                         const float *Wh, int64_t ldw, const float *a, int H, int F, float alpha, int elu, float *Out,

@@ -555,11 +555,18 @@ struct FastDiv {
 // out = att Wh) then move float4s - one ds_read_b128 per four multiply-adds instead of two ds_read_b32 per one.
 __device__ __forceinline__ void gat_logits(int n, int F, int FP, int64_t rld, const float *wh, const float *ah, const float *ablk,
                                            float alpha, float *s1, float *s2, float *att, int tid) {
-    for (int e = tid; e < 2 * n; e += GAT_T) {
-        const int i = e >> 1, w = e & 1;
-        float u = 0.f;
-        for (int f = 0; f < F; ++f) u += wh[i * FP + f] * ah[w * F + f];
-        (w ? s2 : s1)[i] = u;
+    {   // rows of wh and both halves of ah are zero-padded to FP: float4 dot products
+        const float4 *wh4 = reinterpret_cast<const float4 *>(wh), *ah4 = reinterpret_cast<const float4 *>(ah);
+        const int F4 = FP >> 2;
+        for (int e = tid; e < 2 * n; e += GAT_T) {
+            const int i = e >> 1, w = e & 1;
+            float u = 0.f;
+            for (int q = 0; q < F4; ++q) {
+                const float4 x = wh4[i * F4 + q], y = ah4[w * F4 + q];
+                u += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+            }
+            (w ? s2 : s1)[i] = u;
+        }
     }
     __syncthreads();
     const FastDiv dn(n);
@@ -590,12 +597,15 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_fwd_kernel(Scenes sc, const fl
     extern __shared__ __align__(16) float sm[];
     const int s = blockIdx.x, hd = blockIdx.y;
     const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, FP = (F + 3) & ~3, F4 = FP >> 2;
-    float *wh = sm, *s1 = wh + n * FP, *s2 = s1 + n, *att = s2 + n, *ah = att + n * n;
+    float *wh = sm, *ah = wh + n * FP, *s1 = ah + 2 * FP, *s2 = s1 + n, *att = s2 + n;      // ah: [a[:F] | 0.. | a[F:] | 0..], FP each
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
     const FastDiv dFP(FP), dF4(F4);
-    for (int e = tid; e < 2 * F; e += GAT_T) ah[e] = a[(int64_t)hd * 2 * F + e];      // the attention vector: read F times per row below
+    for (int e = tid; e < 2 * FP; e += GAT_T) {                // the attention vector: read F times per row below
+        const int w = e >= FP, f = e - w * FP;
+        ah[e] = f < F ? a[(int64_t)hd * 2 * F + w * F + f] : 0.f;
+    }
     for (int e = tid; e < n * FP; e += GAT_T) {
         const int i = dFP(e), f = e - i * FP;
         wh[e] = f < F ? Wh[(int64_t)(b + i) * ldw + hd * F + f] : 0.f;
@@ -634,13 +644,16 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
     extern __shared__ __align__(16) float sm[];
     const int s = blockIdx.x, hd = blockIdx.y;
     const int b = sc.scene_ptr[s], n = sc.scene_ptr[s + 1] - b, FP = (F + 3) & ~3, F4 = FP >> 2;
-    float *wh = sm, *dO = wh + n * FP, *s1 = dO + n * FP, *s2 = s1 + n, *ds1 = s2 + n, *ds2 = ds1 + n, *dot = ds2 + n;
-    float *att = dot + n, *dpre = att + n * n, *ah = dpre + n * n;
+    float *wh = sm, *dO = wh + n * FP, *ah = dO + n * FP, *s1 = ah + 2 * FP, *s2 = s1 + n, *ds1 = s2 + n, *ds2 = ds1 + n, *dot = ds2 + n;
+    float *att = dot + n, *dpre = att + n * n;
     const float *ablk = adj + sc.off[s];
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
     const FastDiv dFP(FP), dF4(F4), dn(n);
-    for (int e = tid; e < 2 * F; e += GAT_T) ah[e] = a[(int64_t)hd * 2 * F + e];
+    for (int e = tid; e < 2 * FP; e += GAT_T) {
+        const int w = e >= FP, f = e - w * FP;
+        ah[e] = f < F ? a[(int64_t)hd * 2 * F + w * F + f] : 0.f;
+    }
     for (int e = tid; e < n * FP; e += GAT_T) {
         const int ii = dFP(e), f = e - ii * FP;
         float w = 0.f, g = 0.f;
@@ -700,7 +713,7 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int f = 4 * q + c;
-            if (f < F) dWh[(int64_t)(b + j) * ldg + hd * F + f] = o[c] + ds1[j] * ah[f] + ds2[j] * ah[F + f];
+            if (f < F) dWh[(int64_t)(b + j) * ldg + hd * F + f] = o[c] + ds1[j] * ah[f] + ds2[j] * ah[FP + f];
         }
     }
     for (int f = tid; f < 2 * F; f += GAT_T) {

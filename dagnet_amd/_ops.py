@@ -251,9 +251,9 @@ POOL = StepPool()
 
 
 class Branches:
-    """Side streams for the independent branches of a training step (training.forward_train): the prior, the goal head and
-    the decoder / NLL of a time step do not feed the recurrence, so they run beside the encoder -> phi_z -> GRU -> graph
-    chain instead of in line with it.  Every kernel of the step moves ~40 MB in ~17 us and leaves the chip half idle at its
+    """Side streams for the independent branches of a training step (training.forward_train): the goal head and the decoder / NLL
+    of a time step do not feed the recurrence, so they run beside the encoder -> phi_z -> GRU -> graph chain instead of in line
+    with it (the prior could too, but see `inline`).  Every kernel of the step moves ~40 MB in ~17 us and leaves the chip half idle at its
     head and tail; two or three such chains side by side fill those gaps (tools/ubench/graph_branches.py: 3 chains of 12
     GEMMs 598 -> 395 us, also as branches of a captured hipGraph).  The backward pass follows by itself: autograd runs a
     node's backward on the stream of its forward and orders the streams along the edges it knows.  What it does NOT know are
@@ -263,6 +263,10 @@ class Branches:
 
     def __init__(self):
         self.enabled = os.environ.get("DAGNET_TRAIN_STREAMS", "1") != "0"
+        # branches kept on the main stream after all: the prior sits on the loop-carried path (the latent draw needs it going forward,
+        # d h(t-1) needs its backward right after the VAE's), where two stream crossings per time step cost more than the overlap
+        # gives (measured: 117.8 ms forked, 115.8 inline; the decoder either way; the goal head inline: 126.1)
+        self.inline = set(filter(None, os.environ.get("DAGNET_INLINE_BRANCHES", "prior").split(",")))
         self.side = {}
         self.keep = []           # events of the step in flight: one that is destroyed while the hipGraph capture that recorded it is
                                  # still open takes the runtime down at capture end, so they live until the next step begins
@@ -284,7 +288,7 @@ class Branches:
     @contextlib.contextmanager
     def fork(self, name, device):
         """Run the block on side stream ``name``, ordered after everything issued on the current stream so far."""
-        if not (self.enabled and POOL.active):
+        if not (self.enabled and POOL.active) or name in self.inline:
             yield
             return
         st = self._stream(name, device)

@@ -128,8 +128,9 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
             pool.next_t(t)
             x_t = traj_rel[t]
             hl = h[-1]
-            # Three branches of the step feed only losses or the latent draw, not the recurrence: they go to side streams
-            # (_ops.Branches) and run beside the phi_x -> encoder -> phi_z -> GRU -> graph chain.
+            # Three branches of the step feed only losses or the latent draw, not the recurrence: the goal head and the decoder go to
+            # side streams (_ops.Branches) and run beside the phi_x -> encoder -> phi_z -> GRU -> graph chain; the prior is marked as
+            # a branch too but stays on the main stream by default (Branches.inline).
             if kind == "dagnet":
                 d_t = _ops.disposition(plan, traj[t], D)
                 g_prev, g_t = goals[t - 1], goals[t]

@@ -1118,6 +1118,35 @@ class FanoutFn(torch.autograd.Function):
         return buf
 
 
+class UnstackFn(torch.autograd.Function):
+    """[T * M, W] -> T views [M, W] of a matrix computed for all time steps at once (a block that does not depend on the recurrence:
+    phi_x of the whole observed sequence).  Backward: the steps' gradients are StepPool slices of one stacked buffer (the fan-out
+    buffers of the per-step aliases), so the gradient of the whole matrix is a view of that buffer - no copy; anything else is
+    concatenated."""
+
+    @staticmethod
+    def forward(ctx, big, T):
+        M = big.shape[0] // T
+        ctx.shape = tuple(big.shape)
+        ctx.set_materialize_grads(False)
+        return tuple(big[t * M:(t + 1) * M] for t in range(T))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        if all(g is None for g in gs):
+            return None, None
+        R, W = ctx.shape
+        M = R // len(gs)
+        ref = next(g for g in gs if g is not None)
+        gs = [g if g is not None else torch.zeros((M, W), dtype=ref.dtype, device=ref.device) for g in gs]
+        first = gs[0]
+        if all(g.is_contiguous() and g.shape == (M, W) and g.data_ptr() == first.data_ptr() + 4 * i * M * W for i, g in enumerate(gs)):
+            whole = torch.empty(0, dtype=first.dtype, device=first.device)
+            whole.set_(first.untyped_storage(), first.storage_offset(), (R, W), (W, 1))
+            return whole, None
+        return torch.cat([_rows(g) for g in gs], 0), None
+
+
 def fanout(x):
     """-> an alias of x whose consumers share one gradient buffer (only worth it inside a training step)."""
     if not POOL.active or not x.requires_grad:

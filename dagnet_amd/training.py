@@ -8,6 +8,7 @@ over all rows of the batch (gat_model.py:21 in train mode) and updates its runni
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 
 import numpy as np
@@ -122,6 +123,11 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
                 st_goal = _ops.gat_stacks(model.graph_goals)
         h = [torch.zeros((N, R), dtype=torch.float32, device=dev) for _ in range(L)]
         packs = _ops.gru_packs(model.rnn, (H, H))           # the GRU weights in the fused layer kernel's order, once per step
+        # phi_x does not depend on the recurrence: one launch over the whole sequence instead of one per time step
+        phi_x_all = None
+        if T > 1 and os.environ.get("DAGNET_NO_TIME_BATCH") is None:
+            x_all = traj_rel[1:].reshape((T - 1) * N, traj_rel.shape[2])
+            phi_x_all = _ops.UnstackFn.apply(_mlp2(model.phi_x, [x_all], [0]), T - 1)
         k_rows, n_rows, c_rows = [], [], []
         br = _ops.BR
         for t in range(1, T):
@@ -145,7 +151,7 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
                     _, mu_p, lv_p = _mlp2_heads(model.prior, model.prior_mean, model.prior_logvar, [hl], [G], gidx=g_t, gcol=0, gdim=G)
                 else:
                     _, mu_p, lv_p = _mlp2_heads(model.prior, model.prior_mean, model.prior_logvar, [hl], [0])
-            phi_x = fan(_mlp2(model.phi_x, [x_t], [0]))
+            phi_x = fan(phi_x_all[t - 1] if phi_x_all is not None else _mlp2(model.phi_x, [x_t], [0]))
             if kind == "dagnet":
                 _, mu_e, lv_e = _mlp2_heads(model.enc, model.enc_mean, model.enc_logvar, [phi_x, hl], [0, H + G], gidx=g_t, gcol=H, gdim=G)
             else:

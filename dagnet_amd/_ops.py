@@ -23,7 +23,7 @@ ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 OP_EXPORTS = (
     "dagnet_op_gemm", "dagnet_op_gemm_dact", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
     "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_mlp_chain_fwd", "dagnet_op_mlp2_bwd", "dagnet_op_linear_pieces_bwd", "dagnet_op_set_fused", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
-    "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd",
+    "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd", "dagnet_op_softmax_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
     "dagnet_op_gat_attn_fwd", "dagnet_op_gat_attn_bwd", "dagnet_op_adj_matmul", "dagnet_op_disposition", "dagnet_op_sumsq",
     "dagnet_op_adam",
@@ -69,6 +69,7 @@ def _lib():
         lib.dagnet_op_nll_bwd.argtypes = [i64, i32, vp, vp, vp, vp, f32, vp, vp, vp]
         lib.dagnet_op_ce_fwd.argtypes = [i64, vp, i64, vp, vp, vp]
         lib.dagnet_op_ce_bwd.argtypes = [i64, i32, vp, vp, vp, i64, vp]
+        lib.dagnet_op_softmax_ce_bwd.argtypes = [i64, i32, vp, i64, vp, vp, vp, i64, vp]
         lib.dagnet_op_sum.argtypes = [i64, vp, f32, vp, i32, vp]
         lib.dagnet_op_col_workspace.argtypes = [i64, i32]
         lib.dagnet_op_col_workspace.restype = i64
@@ -1064,6 +1065,33 @@ class CeFn(torch.autograd.Function):
         dp = POOL.at(ctx.slot, "dp", (M, G), goal, dtype=torch.float32)
         _check(_lib().dagnet_op_ce_bwd(M, G, _p(goal), _scalar_grad(g), _p(dp), dp.stride(0), _stream(goal.device)))
         return dp, None
+
+
+class SoftmaxCeFn(torch.autograd.Function):
+    """Per row -softmax(x)[row, goal[row]]: nn.Softmax followed by the reference's probability "cross entropy"
+    (models/dagnet/model.py:100,162) with a one-kernel backward (SoftmaxFn + CeFn: a [M, G] one-hot gradient and a softmax backward
+    over it)."""
+
+    @staticmethod
+    def forward(ctx, x, goal):
+        ctx.slot = POOL.site()
+        M, G = x.shape
+        y = POOL.at(ctx.slot, "y", (M, G), x)
+        rows = POOL.at(ctx.slot, "rows", (M,), x)
+        (xp, ldx), (yp, ldy) = _m(x), _m(y)
+        _check(_lib().dagnet_op_softmax_fwd(M, G, xp, ldx, yp, ldy, _stream(x.device)))
+        _check(_lib().dagnet_op_ce_fwd(M, yp, ldy, _p(goal), _p(rows), _stream(x.device)))
+        ctx.save_for_backward(y, goal)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        y, goal = ctx.saved_tensors
+        M, G = y.shape
+        dx = POOL.at(ctx.slot, "dx", (M, G), y)
+        (yp, ldy), (xp, ldx) = _m(y), _m(dx)
+        _check(_lib().dagnet_op_softmax_ce_bwd(M, G, yp, ldy, _p(goal), _scalar_grad(g), xp, ldx, _stream(y.device)))
+        return dx, None
 
 
 class _GradAcc:

@@ -1840,6 +1840,14 @@ extern "C" int dagnet_op_ce_fwd(int64_t M, const float *p, int64_t ldp, const in
     HIP_TRY(dn_t_ce_fwd(M, p, ldp, goal, ce_row, OP_ST));
     return DAGNET_OK;
 }
+extern "C" hipError_t dn_t_softmax_ce_bwd(int64_t M, int G, const float *p, int64_t ldp, const int32_t *goal, const float *g, float *dx,
+                                          int64_t ldx, hipStream_t st);
+extern "C" int dagnet_op_softmax_ce_bwd(int64_t M, int32_t G, const float *p, int64_t ldp, const int32_t *goal, const float *g, float *dx,
+                                        int64_t ldx, void *stream) {
+    OP_NEED(M >= 0 && G >= 1 && (M == 0 || (p && goal && g && dx)), "bad argument");
+    HIP_TRY(dn_t_softmax_ce_bwd(M, G, p, ldp, goal, g, dx, ldx, OP_ST));
+    return DAGNET_OK;
+}
 extern "C" int dagnet_op_ce_bwd(int64_t M, int32_t G, const int32_t *goal, const float *g, float *dp, int64_t ldp, void *stream) {
     OP_NEED(M >= 0 && G >= 1 && (M == 0 || (goal && g && dp)), "bad argument");
     HIP_TRY(dn_t_ce_bwd(M, G, goal, g, dp, ldp, OP_ST));

@@ -248,6 +248,19 @@ __global__ void ce_fwd_kernel(int64_t M, const float *__restrict__ p, int64_t ld
     ce_row[m] = -p[m * ldp + goal[m]];
 }
 
+// backward of rows[m] = -softmax(x)[m][goal[m]] in one pass: dx[m][c] = g p[m][c] (p[m][goal] - [c == goal])   (the one-hot gradient
+// of the probabilities and the softmax backward over it were two kernels and a [M, G] matrix of zeros)
+__global__ void softmax_ce_bwd_kernel(int64_t M, int G, const float *__restrict__ p, int64_t ldp, const int32_t *__restrict__ goal,
+                                      const float *__restrict__ g_ce, float *__restrict__ dx, int64_t ldx) {
+    const int64_t i = gid();
+    if (i >= M * G) return;
+    const int64_t m = i / G;
+    const int c = (int)(i - m * G);
+    const int gl = goal[m];
+    const float pg = p[m * ldp + gl];
+    dx[m * ldx + c] = g_ce[0] * p[m * ldp + c] * (pg - (c == gl ? 1.f : 0.f));
+}
+
 __global__ void ce_bwd_kernel(int64_t M, int G, const int32_t *__restrict__ goal, const float *__restrict__ g_ce, float *__restrict__ dp,
                               int64_t ldp) {
     const int64_t i = gid();
@@ -1011,6 +1024,12 @@ extern "C" hipError_t dn_t_nll_bwd(int64_t M, int X, const float *mu, const floa
 extern "C" hipError_t dn_t_ce_fwd(int64_t M, const float *p, int64_t ldp, const int32_t *goal, float *ce_row, hipStream_t st) {
     if (M == 0) return hipSuccess;
     hipLaunchKernelGGL(tops::ce_fwd_kernel, T_GRID(M), 0, st, M, p, ldp, goal, ce_row);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_t_softmax_ce_bwd(int64_t M, int G, const float *p, int64_t ldp, const int32_t *goal, const float *g, float *dx,
+                                          int64_t ldx, hipStream_t st) {
+    if (M * G == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::softmax_ce_bwd_kernel, T_GRID(M * G), 0, st, M, G, p, ldp, goal, g, dx, ldx);
     return hipGetLastError();
 }
 extern "C" hipError_t dn_t_ce_bwd(int64_t M, int G, const int32_t *goal, const float *g, float *dp, int64_t ldp, hipStream_t st) {

@@ -144,8 +144,7 @@ def forward_train(model, scene_ptr, traj_rel, traj=None, goals=None, adj=None, e
                     hid = linear(model.dec_goal[0], [d_t, hl], [0, D], act=ACT_RELU, gidx=g_prev, gcol=D + R, gdim=G)
                     dec_g = fan(SoftmaxFn.apply(linear(model.dec_goal[2], [hid], [0])))
                     g_graph = _graph(model.graph_goals, dec_g, adj[t], plan, st_goal)
-                    g_comb = SoftmaxFn.apply(linear(model.lg_goals[0], [dec_g, g_graph], [0, G]))
-                    c_rows.append(CeFn.apply(g_comb, g_t))
+                    c_rows.append(_ops.SoftmaxCeFn.apply(linear(model.lg_goals[0], [dec_g, g_graph], [0, G]), g_t))
             with br.fork("prior", dev):             # prior: joins at the latent draw
                 if kind == "dagnet":
                     _, mu_p, lv_p = _mlp2_heads(model.prior, model.prior_mean, model.prior_logvar, [hl], [G], gidx=g_t, gcol=0, gdim=G)

@@ -305,6 +305,10 @@ int dagnet_op_nll_bwd(int64_t M, int32_t X, const float *mu, const float *lv, co
 /* Replaces: cross_entropy -= sum(g_t * g_combined) (models/dagnet/model.py:162): ce_row[m] = -p[m][goal[m]]. */
 int dagnet_op_ce_fwd(int64_t M, const float *p, int64_t ldp, const int32_t *goal, float *ce_row, void *stream);
 int dagnet_op_ce_bwd(int64_t M, int32_t G, const int32_t *goal, const float *g, float *dp, int64_t ldp, void *stream);
+/* The backward of ce_row = -softmax(x)[m][goal[m]] (lg_goals' softmax followed by the probability "cross entropy", model.py:100,162) in
+ * one pass from the saved probabilities p: dx[m][c] = g[0] p[m][c] (p[m][goal[m]] - [c == goal[m]]). */
+int dagnet_op_softmax_ce_bwd(int64_t M, int32_t G, const float *p, int64_t ldp, const int32_t *goal, const float *g, float *dx, int64_t ldx,
+                             void *stream);
 /* out[0] (+)= scale * sum(x) in fp64, fixed order (loss scalars). */
 int dagnet_op_sum(int64_t n, const float *x, float scale, float *out, int32_t accumulate, void *stream);
 /* Column sums over the rows (bias gradients): out[c] (+)= sum_m X[m][c]; workspace: dagnet_op_col_workspace(M, N) floats. */

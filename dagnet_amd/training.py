@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _capi, _ops
-from ._ops import ACT_LRELU, ACT_NONE, ACT_RELU, CeFn, LossSumFn, NllFn, SoftmaxFn, VaeFn, gat_train, gcn_train, gru_step, linear
+from ._ops import ACT_LRELU, ACT_NONE, ACT_RELU, LossSumFn, NllFn, SoftmaxFn, VaeFn, gat_train, gcn_train, gru_step, linear
 
 _PLANS: "OrderedDict[tuple, _capi.HipPlan]" = OrderedDict()
 

@@ -32,6 +32,9 @@ from dagnet_amd import _capi, synthetic as syn       # noqa: E402
 from dagnet_amd._runtime import scene_ptr_from_sse   # noqa: E402
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+# The wide layers of the g_dim = 960 goal head multiply on the bf16 matrix pipe: three bf16 terms per fp32 value, six bf16 products
+# per fp32 product (csrc/gemm_f32.hip, BF3).  Their bound in fp32-equivalent FLOP/s is the dense bf16 peak (2.5 PFLOP/s) / 6.
+PEAK_SPLIT_BF16_TFLOPS = 2500.0 / 6.0
 
 
 def pmc_traffic(workload, kernel):
@@ -526,6 +529,8 @@ def main():
             launch_flop /= n_chunks
         achieved = launch_flop / (kernel_ms * 1e-3) / 1e12
         info = model.hip_plan(dev, np.ascontiguousarray(plan_sp - plan_sp[0]), K).info()
+        split_bf16 = "wide goal head" in info["sample_kernel"] and not os.environ.get("DAGNET_NO_BF16X3")
+        peak = PEAK_SPLIT_BF16_TFLOPS if split_bf16 else PEAK_FP32_MATRIX_TFLOPS
         line = {
             "metric": "sampled trajectories/sec (best-of-20 rollout)", "value": value, "unit": "trajectories/s",
             "n_gpus": world_seen, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
@@ -535,8 +540,9 @@ def main():
                        "chunks_per_step": n_chunks, "scenes_per_chunk": chunk,
                        "tile_rows": info["tile_rows"], "tiles": info["n_tiles"], "lds_bytes": info["lds_bytes"],
                        "parallelism": f"scenes sharded x{world_seen}, 1 all-reduce of 3 doubles per step"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MATRIX_TFLOPS,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                         "frac": achieved / peak,
+                         "peak_kind": "bf16 dense / 6 products (split-bf16 wide layers)" if split_bf16 else "fp32 matrix",
                          "traffic": pmc_traffic("dagnet_bsk_4096x20" if strong else opt.workload, info["sample_kernel"]),
                          "kernel": info["sample_kernel"], "kernel_ms": kernel_ms,
                          "flop_per_trajectory": fl},

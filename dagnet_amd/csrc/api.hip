@@ -1660,7 +1660,8 @@ extern "C" int dagnet_op_gru_fwd(int64_t M, int32_t R, const float *gi, const fl
 // All on unless DAGNET_NO_GRU_FUSED / DAGNET_NO_MLP_FUSED / DAGNET_NO_MLP_BWD_FUSED is set; dagnet_op_set_fused changes it at run
 // time (the tests compare a training step with and without them).
 static int fused_default() {
-    return (getenv("DAGNET_NO_GRU_FUSED") ? 0 : 1) | (getenv("DAGNET_NO_MLP_FUSED") ? 0 : 2) | (getenv("DAGNET_NO_MLP_BWD_FUSED") ? 0 : 4);
+    return (getenv("DAGNET_NO_GRU_FUSED") ? 0 : 1) | (getenv("DAGNET_NO_MLP_FUSED") ? 0 : 2) | (getenv("DAGNET_NO_MLP_BWD_FUSED") ? 0 : 4) |
+           (getenv("DAGNET_NO_BF16X3") ? 0 : 8);
 }
 static std::atomic<int> g_fused{-1};
 static int fused_mask() {
@@ -1671,9 +1672,12 @@ static int fused_mask() {
     }
     return m;
 }
+extern "C" int dn_gemm_set_bf16x3(int on);      // gemm_f32.hip: bit 3, split-bf16 products in the wide (N > 96) layers
 extern "C" int dagnet_op_set_fused(int32_t mask) {
     const int before = fused_mask();
-    g_fused.store(mask < 0 ? fused_default() : (mask & 7), std::memory_order_relaxed);
+    const int now = mask < 0 ? fused_default() : (mask & 15);
+    g_fused.store(now, std::memory_order_relaxed);
+    dn_gemm_set_bf16x3((now >> 3) & 1);
     return before;
 }
 extern "C" hipError_t dn_gru_fused_fwd(int64_t M, int R, int npieces, const float *x0, int64_t ldx0, const float *x1, int64_t ldx1,

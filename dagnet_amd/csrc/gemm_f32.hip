@@ -221,14 +221,28 @@ __device__ __forceinline__ i32x4 gp_rsrc(const float *base, int64_t bytes) {
 }
 
 // BKP: k-chunk (32 or 16), WPC: workgroups per CU the registers are budgeted for (LDS: 2 * 256 * (BKP + 4) * 4 bytes each)
-template <int BKP, int WPC>
+//
+// BF3 (k-chunks of 16): the same products on the bf16 matrix pipe.  Both operands are split where they are staged into LDS, each
+// fp32 value into three bf16 terms by truncation (v_and / v_sub / v_perm: 8 + 8 + 8 significant bits, so hi + mid + lo is the
+// value exactly), and a chunk is six v_mfma_f32_32x32x16_bf16 per accumulator tile - hi.hi, hi.mid, mid.hi, mid.mid, hi.lo,
+// lo.hi; the three dropped products are below 2^-24 of the largest - with fp32 accumulation: 24 x 32 clocks per wave and chunk
+// where the fp32 form takes 32 x 64.  Measured on a chain of layers against fp64 (tools/ubench/split_bf16.hip,
+// profiles/r02_split_bf16.txt): half the error of v_mfma_f32_32x32x2_f32.  A non-finite input comes out as NaN (inf - inf
+// in the split) where the fp32 form would carry the infinity.
+// LDS: [buffer 2][term 3][row 128][16 bf16 + pad] per operand, row stride 12 dwords (16 rows x 16 B cover the 64 banks once).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BF3_RS = 12, BF3_PL = 128 * BF3_RS, BF3_OPB = 3 * BF3_PL;      // dwords: row, plane, operand buffer
+constexpr size_t BF3_LDS = (size_t)4 * BF3_OPB * 4;                            // bytes: two operands, two buffers
+template <int BKP, int WPC, bool BF3 = false>
 __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) {
+    static_assert(!BF3 || BKP == 16, "the split-bf16 form takes one 16-deep k block per chunk");
     constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
     constexpr int LDP = BKP + 4;                 // LDS row stride (floats): 16 rows x 16 B cover the 64 banks once for 36 and for 20
     constexpr int TPR = BKP / 4, RPP = 256 / TPR, NL = 128 / RPP;      // loader: threads per row, rows per pass, passes
     extern __shared__ float smem[];
-    float *sA = smem;                       // [2][BM][LDP]
-    float *sB = smem + 2 * BM * LDP;        // [2][BN][LDP]
+    float *sA = smem;                                             // [2][BM][LDP]
+    float *sB = smem + (BF3 ? 2 * BF3_OPB : 2 * BM * LDP);        // [2][BN][LDP]
+    unsigned *uA = reinterpret_cast<unsigned *>(sA), *uB = reinterpret_cast<unsigned *>(sB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int lr = lane & 31, lh = lane >> 5;
@@ -270,11 +284,34 @@ __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) 
             set_desc(ltile);
         }
     };
+    // four consecutive k of one row -> 4 bf16 (8 bytes) in each of the three term planes
+    auto split_store = [&](unsigned *dst, f32x4 v) {
+        float e[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            unsigned u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[k] = __builtin_bit_cast(unsigned, e[k]);
+            const uint2 pk = {__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u)};
+            *reinterpret_cast<uint2 *>(dst + t * BF3_PL) = pk;
+            if (t < 2) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) e[k] -= __builtin_bit_cast(float, u[k] & 0xffff0000u);
+            }
+        }
+    };
     auto sstore = [&](int buf) {
+        if constexpr (BF3) {
 #pragma unroll
-        for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4 *>(sA + (buf * BM + lrow + RPP * i) * LDP + lc4) = ga[i];
+            for (int i = 0; i < NL; ++i) split_store(uA + buf * BF3_OPB + (lrow + RPP * i) * BF3_RS + (lc4 >> 1), ga[i]);
 #pragma unroll
-        for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4 *>(sB + (buf * BN + lrow + RPP * i) * LDP + lc4) = gb[i];
+            for (int i = 0; i < NL; ++i) split_store(uB + buf * BF3_OPB + (lrow + RPP * i) * BF3_RS + (lc4 >> 1), gb[i]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4 *>(sA + (buf * BM + lrow + RPP * i) * LDP + lc4) = ga[i];
+#pragma unroll
+            for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4 *>(sB + (buf * BN + lrow + RPP * i) * LDP + lc4) = gb[i];
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -293,6 +330,30 @@ __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) 
     int buf = 0, kc = 0;
     int m0 = (int)(tile / nbn) * BM, n0 = (int)(tile % nbn) * BN;
     while (true) {
+      if constexpr (BF3) {
+        // this chunk's operands, in the order of their first use: 8 k of one row per lane and term
+        const unsigned *a_base = uA + buf * BF3_OPB + ((wm * TM) * 32 + lr) * BF3_RS + 4 * lh;
+        const unsigned *b_base = uB + buf * BF3_OPB + ((wn * TN) * 32 + lr) * BF3_RS + 4 * lh;
+        bf16x8 fa[3][TM], fb[3][TN];
+        auto rd = [](const unsigned *q) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(q)); };
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int a = 0; a < TM; ++a) fa[t][a] = rd(a_base + t * BF3_PL + a * 32 * BF3_RS);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[t][b] = rd(b_base + t * BF3_PL + b * 32 * BF3_RS);
+        }
+        sstore(buf ^ 1);        // chunk q + 1, split on the way
+        gload();                // chunk q + 2
+        constexpr int PA[6] = {0, 0, 1, 1, 0, 2}, PB[6] = {0, 1, 0, 1, 2, 0};
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][a], fb[PB[q]][b], acc[a][b], 0, 0, 0);
+      } else {
         sstore(buf ^ 1);        // chunk q + 1 -> the buffer that chunk q - 1 was read from (all waves passed the barrier since)
         gload();                // chunk q + 2
         const float *a_base = sA + (buf * BM + (wm * TM) * 32 + lr) * LDP + 4 * lh;
@@ -321,6 +382,7 @@ __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) 
                     for (int b = 0; b < TN; ++b)
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][a][i], fb[j & 1][b][i], acc[a][b], 0, 0, 0);
         }
+      }
         if (++kc == nk) {
             // epilogue: lane = output column, register r <-> row (r&3) + 8(r>>2) + 4h of the 32x32 tile
             if (!p.gather && !p.accumulate) {
@@ -713,11 +775,26 @@ static hipError_t launch_nt_cfg(const NtArgs &a, bool veca, bool vecb, bool tran
     return hipErrorInvalidValue;
 }
 
+// split-bf16 products for the wide layers: on unless DAGNET_NO_BF16X3 is set; dn_gemm_set_bf16x3 switches at run time (tests)
+static int g_bf16x3 = -1;
+static bool bf16x3_on() {
+    if (g_bf16x3 < 0) g_bf16x3 = getenv("DAGNET_NO_BF16X3") ? 0 : 1;
+    return g_bf16x3 != 0;
+}
+
 static hipError_t launch_nt_pipe(const NtArgs &a, hipStream_t st) {
     constexpr int BM = 128, BN = 128;
     const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
     // k-chunks of 16 with three workgroups per CU (41 KB of LDS each) measured 4 % faster on the 1920 -> 960 layer than chunks
     // of 32 with two: 127.5 against 122.3 TFLOP/s at 122 880 rows (tools/ubench/gemm_bench.py)
+    if (bf16x3_on()) {          // 72 KB of LDS: two workgroups per CU
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_pipe_kernel<16, 2, true>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF3_LDS);
+        if (attr != hipSuccess) return attr;
+        const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, 256 * 2);
+        hipLaunchKernelGGL((gemm_nt_pipe_kernel<16, 2, true>), dim3((unsigned)blocks), dim3(256), BF3_LDS, st, a);
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)2 * (BM + BN) * 20 * sizeof(float);
     const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, 256 * 3);
     hipLaunchKernelGGL((gemm_nt_pipe_kernel<16, 3>), dim3((unsigned)blocks), dim3(256), lds, st, a);
@@ -760,6 +837,12 @@ extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64
     if (N > 64) return gemm::launch_nt_cfg<4, 1, 1, 3>(a, veca, vecb, transb != 0, st);
     if (N > 32) return gemm::launch_nt_cfg<2, 2, 1, 1>(a, veca, vecb, transb != 0, st);     // 64 x 64 (measured: 7 % of a training step over 128 x 64)
     return gemm::launch_nt_cfg<4, 1, 1, 1>(a, veca, vecb, transb != 0, st);                 // 128 x 32
+}
+
+extern "C" int dn_gemm_set_bf16x3(int on) {
+    const int before = gemm::bf16x3_on() ? 1 : 0;
+    gemm::g_bf16x3 = on < 0 ? (getenv("DAGNET_NO_BF16X3") ? 0 : 1) : (on ? 1 : 0);
+    return before;
 }
 
 extern "C" hipError_t dn_gemm_nt_gather(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *C,

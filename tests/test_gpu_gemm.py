@@ -61,6 +61,38 @@ def test_gemm_matches_torch(M, N, K, transb):
     torch.testing.assert_close(C.double(), want, **tol)
 
 
+@pytest.mark.parametrize("M,N,K", [(3000, 960, 1920), (1111, 200, 64), (4096, 960, 960)])
+def test_wide_gemm_split_bf16_is_as_exact_as_fp32(M, N, K):
+    """The wide layers multiply on the bf16 matrix pipe (three bf16 terms per value, six products, fp32 accumulation:
+    csrc/gemm_f32.hip, BF3).  Against fp64 the result must be no worse than the fp32 MFMA's on the same operands, also when the
+    values span many binades, and a NaN must still come out as NaN."""
+    g = torch.Generator().manual_seed(N + K)
+    A = (torch.randn((M, K), generator=g) * torch.exp2(torch.randint(-12, 12, (M, K), generator=g).float())).to(DEV)
+    W = (torch.randn((N, K), generator=g) / K ** 0.5).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = A.double() @ W.double().t() + bias.double()
+    scale = (A.double().abs() @ W.double().abs().t()).clamp_min(1e-30)          # what the rounding errors are relative to
+    out = {}
+    before = _ops.set_fused(-1)
+    try:
+        for mask in (15, 7):
+            _ops.set_fused(mask)
+            C = torch.empty((M, N), device=DEV)
+            _ops.gemm(A, W, C, bias=bias)
+            out[mask] = C
+        A[5, 7] = float("nan")
+        _ops.set_fused(15)
+        C = torch.empty((M, N), device=DEV)
+        _ops.gemm(A, W, C, bias=bias)
+        assert bool(torch.isnan(C[5]).all()) and not bool(torch.isnan(C[6]).any())
+    finally:
+        _ops.set_fused(before)
+    e_bf = float(((out[15].double() - ref).abs() / scale).max())
+    e_f32 = float(((out[7].double() - ref).abs() / scale).max())
+    assert e_bf <= max(1.5 * e_f32, 2e-7), (e_bf, e_f32)
+    assert e_bf < 1e-6, e_bf
+
+
 @pytest.mark.parametrize("M,N,K", [(40960, 64, 64), (5001, 192, 64), (2049, 32, 64), (3000, 64, 32), (7001, 90, 90), (4100, 90, 64),
                                    (2500, 90, 32), (2100, 32, 90), (3333, 64, 20), (2048, 2, 64), (2300, 64, 2), (100, 64, 64), (31, 50, 64),
                                    (3000, 33, 64), (2600, 64, 130), (2200, 128, 64), (1, 64, 64), (2500, 160, 64), (9000, 96, 96)])

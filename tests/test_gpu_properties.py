@@ -326,6 +326,29 @@ def test_wide_goal_head_agrees_with_generic_kernel_on_ragged_sdd_batch(adj_kw):
     assert torch.equal(s2, s_w), "the wide path is not deterministic for a fixed seed"
 
 
+def test_wide_goal_head_split_bf16_matches_fp32_products():
+    """The wide layers of the g_dim = 960 head on the bf16 matrix pipe (three-term split: csrc/gemm_f32.hip BF3) against the
+    same head on fp32 MFMAs: same goals except near-ties, same trajectories to fp32 noise."""
+    from dagnet_amd import _ops
+    a, m, _ = _model("dagnet", n_max=32, seed=9, n_layers=2, g_dim=960)
+    sizes = [int(v) for v in syn.ragged_sizes(60, seed=5)]
+    N, K, T = sum(sizes), 3, 6
+    batch = [t.to(DEV) for t in syn.make_batch(sizes, 8, T, 4, kind="sdd", g_cells=(32, 30))]
+    h = (syn.uniform_noise(5, "h0", (2, N, 64)) - 0.5).to(DEV)
+    out = {}
+    before = _ops.set_fused(-1)
+    try:
+        for mask in (15, 7):
+            _ops.set_fused(mask)
+            out[mask] = _sample_k("dagnet", m, K, T, h, batch, return_goals=True, seed=33)
+    finally:
+        _ops.set_fused(before)
+    (s_b, g_b), (s_f, g_f) = out[15], out[7]
+    same = (g_b == g_f).all(dim=1, keepdim=True).expand_as(g_b)
+    assert same.float().mean() > 0.99
+    assert float((s_b - s_f).abs().amax(dim=-1)[same].max()) < 1e-4
+
+
 @pytest.mark.parametrize("kind,kw", [("vrnn", dict(n_layers=2)), ("avrnn", dict(n_layers=1)), ("dagnet", dict(n_layers=2)),
                                      ("avrnn", dict(n_layers=2, graph_model="gcn")), ("dagnet", dict(n_layers=2, graph_model="gcn"))])
 @pytest.mark.parametrize("compact", [False, True])

@@ -193,7 +193,7 @@ def cpu_baseline_stock(wl, kind=None, scenes=32, budget_s=10.0):
         m.sample(T, h.clone(), obs[-1] if kind != "vrnn" else None, g0, sse)
         done += 1
     dt = time.perf_counter() - t0
-    return dict(value=N * done / dt, unit="trajectories/s", cores=torch.get_num_threads(), kind="port",
+    return dict(value=N * done / dt, unit="trajectories/s", cores=torch.get_num_threads(), kind="torch.nn dense-GAT",
                 sample=f"{kind}: {scenes} scenes x {n} agents x {done} samples x {T} steps, stock torch.nn layers with the reference's dense "
                        "[N,N,2F] graph attention and per-scene scipy adjacency (oracle/stock_torch.py), torch CPU fp32")
 
@@ -321,13 +321,35 @@ def device_batch(S, n, obs_len, pred_len, seed, dev):
             goals[:obs_len].contiguous(), goals[obs_len:].contiguous(), torch.stack((st, st + n), 1))
 
 
+def visible_gpu_count(sysfs="/sys/class/kfd/kfd/topology/nodes", env=None):
+    """GPUs this process's children can use, counted WITHOUT any HIP call (torch.cuda.device_count() falls back to
+    hipGetDeviceCount when its amdsmi discovery fails, and that initialises HIP in a parent that is about to start children):
+    KFD topology nodes with SIMDs (CPU nodes report simd_count 0), cut down by HIP_ / ROCR_ / CUDA_VISIBLE_DEVICES.
+    None when the topology cannot be read (no amdgpu driver): the ranks then fail loudly by themselves in set_device()."""
+    env = os.environ if env is None else env
+    try:
+        n = 0
+        for node in sorted(os.listdir(sysfs)):
+            with open(os.path.join(sysfs, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+    except (OSError, ValueError):
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        if var in env:
+            n = min(n, len([v for v in env[var].split(",") if v.strip()]))
+    return n
+
+
 def self_launch(opt, argv):
     """--gpus N > 1 without a launcher: start N ranks of this script (one per GPU) and relay rank 0's output.  Runs BEFORE
-    anything touches the GPU in this process, which only waits (never exec from a process that initialised the GPU)."""
+    anything touches the GPU in this process, which only waits (never exec from a process that initialised the GPU) and
+    makes no HIP call of its own, not even to count devices."""
     import socket
     import subprocess
-    if not opt.rehearse and torch.cuda.device_count() < opt.gpus:        # device_count() does not initialise the GPU
-        raise SystemExit(f"--gpus {opt.gpus} but only {torch.cuda.device_count()} visible")
+    have = None if opt.rehearse else visible_gpu_count()
+    if have is not None and have < opt.gpus:
+        raise SystemExit(f"--gpus {opt.gpus} but only {have} visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -350,6 +372,16 @@ def self_launch(opt, argv):
                 if other.poll() is None:
                     other.kill()
     raise SystemExit(rc)
+
+
+def walk_cap(n_chunks, steps, warmup, budget=1024):
+    """(steps, warmup) of a chunked workload so that (steps + warmup) * n_chunks stays near ``budget`` chunk launches:
+    at least one timed walk, at most one warm-up walk when the request does not fit."""
+    walks = max(2, budget // max(1, n_chunks))
+    if steps + warmup <= walks:
+        return steps, warmup
+    w = min(warmup, 1)
+    return max(1, min(steps, walks - w)), w
 
 
 def rehearse(opt, wl, rank, world):
@@ -408,6 +440,12 @@ def main():
     dist = None
     if world > 1 or os.environ.get("DAGNET_BENCH_FORCE_DIST"):      # the env switch exercises the RCCL path on one GPU
         import torch.distributed as dist
+        # RCCL writes its version banner to the process's stdout (fd 1) at init; the contract is ONE JSON line there.  From here
+        # on fd 1 is the old stderr; print() of the JSON line goes to a duplicate of the real stdout.
+        sys.stdout.flush()
+        real_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+        sys.stdout = real_out
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         world_seen = dist.get_world_size()
@@ -460,6 +498,12 @@ def main():
     fwd_ms = (time.perf_counter() - t0) * 1e3
     x0, g0 = obs[-1].contiguous(), goals[-1].contiguous()
     n_chunks = (S + chunk - 1) // chunk
+    steps_requested, warmup_requested = opt.steps, opt.warmup
+    if n_chunks > 1:
+        # a step of the chunked workload is a WALK of n_chunks launches (256 on one GPU: ~20 s): the driver's --steps 20 --warmup 5
+        # would not fit its time limit, so walks are capped at ~1024 chunk launches per run (8 ranks: 32 chunks per walk, no cap
+        # at 20 + 5); the line reports the steps actually timed and the request
+        opt.steps, opt.warmup = walk_cap(n_chunks, opt.steps, opt.warmup)
     n_dev = torch.tensor([float(n_rows)], dtype=torch.float64, device=dev)
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(opt.steps)]
     plan_sp = sp[:chunk + 1] if n_chunks > 1 else sp
@@ -534,7 +578,10 @@ def main():
         line = {
             "metric": "sampled trajectories/sec (best-of-20 rollout)", "value": value, "unit": "trajectories/s",
             "n_gpus": world_seen, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            # fp32 in, fp32 out, fp32 accumulation; where the products run on the bf16 matrix pipe (three bf16 terms per fp32
+            # value, six products: error <= the fp32 MFMA's) the label says so
+            "dtype": "f32 (bf16x3 products)" if split_bf16 else "f32", "data": "synthetic",
             "config": {"workload": opt.workload, "model": wl["kind"], "scenes_per_gpu": S, "agents_per_scene": n,
                        "samples": K, "obs_len": wl["obs"], "pred_len": T, "rows_per_gpu": n_rows * K,
                        "chunks_per_step": n_chunks, "scenes_per_chunk": chunk,
@@ -546,7 +593,7 @@ def main():
                          "traffic": pmc_traffic("dagnet_bsk_4096x20" if strong else opt.workload, info["sample_kernel"]),
                          "kernel": info["sample_kernel"], "kernel_ms": kernel_ms,
                          "flop_per_trajectory": fl},
-            "forward_obs_ms": fwd_ms,
+            "forward_obs_ms": fwd_ms, "steps_requested": steps_requested, "warmup_requested": warmup_requested,
             "ade": float(tot[0] / (tot[2] * T)), "fde": float(tot[1] / tot[2]),
         }
         if n_chunks == 1 and not opt.no_reference_loop:

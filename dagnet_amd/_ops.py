@@ -200,15 +200,22 @@ class StepPool:
       * the saved input and the pre-activation gradient of a layer are contiguous over time, so its weight gradient is ONE
         [T*M, N]^T [T*M, K] product at the end of the backward pass (DeferredGrads) instead of one product per step;
       * no allocator traffic inside the step, and fixed addresses for hipGraph capture.
-    Inactive (no training.forward_train in flight): plain torch.empty."""
+    Inactive (no training.forward_train in flight): plain torch.empty.
+
+    ONE step in flight: the buffers are reused by the next train-mode forward, so the backward of a graph must run before
+    another forward_train begins (gradient accumulation over two forwards, a logging forward in train mode ... would read
+    the second forward's activations: the kernels write through raw pointers, autograd's version counters see nothing).
+    Every slot carries the generation of the begin() that issued it; a backward that arrives with a stale one raises."""
 
     def __init__(self):
         self.bufs = {}
         self.T, self.t, self.n_site, self.active, self.device = 0, 0, 0, False, None
+        self.gen = 0
 
     def begin(self, T, device):
         """Sites reserved before the first next_t() are per-step (one slot): stacked weights, loop invariants."""
         self.T, self.t, self.n_site, self.active, self.device = int(T), -1, 0, True, torch.device(device)
+        self.gen += 1
         BR.keep.clear()
 
     def next_t(self, t):
@@ -223,13 +230,17 @@ class StepPool:
             return None
         self.n_site += 1
         if self.t < 0:
-            return (("pre", self.n_site - 1), 0, 1)
-        return (self.n_site - 1, self.t, self.T)
+            return (("pre", self.n_site - 1), 0, 1, self.gen)
+        return (self.n_site - 1, self.t, self.T, self.gen)
 
     def at(self, slot, tag, shape, like=None, dtype=torch.float32):
         shape = tuple(int(v) for v in shape)
         if slot is None:
             return torch.empty(shape, dtype=dtype, device=like.device if like is not None else self.device)
+        if slot[3] != self.gen:
+            raise RuntimeError("a train-mode forward has begun since this graph was built: its saved activations live in the "
+                               "step pool (dagnet_amd/_ops.StepPool) and have been overwritten - run backward() before the next "
+                               "train-mode forward (one training step in flight)")
         # rows of wide matrices are padded to 16 bytes (g_dim = 90 -> row stride 92): float4 rows for the skinny GEMM
         pad = len(shape) == 2 and shape[1] > 16 and (shape[1] & 3) != 0
         full = (shape[0], (shape[1] + 3) & ~3) if pad else shape

@@ -56,6 +56,18 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 __device__ f32x4 sk_load4(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.v4f32");
 __device__ float sk_load1(i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.load.f32");
 __device__ void sk_store4(f32x4 data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.v4f32");
+__device__ void sk_store1(float data, i32x4 rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.buffer.store.f32");
+// a quad of columns c0 .. c0+3 of a row whose matrix has `cols` columns: whole quads as one 16-byte store, the one quad that
+// straddles the last column element by element - columns >= cols belong to the caller (a column slice of a wider buffer)
+__device__ __forceinline__ void sk_store_quad(f32x4 v, i32x4 rsrc, int voff, int c0, int cols) {
+    if (c0 + 4 <= cols) {
+        sk_store4(v, rsrc, voff, 0, 0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (c0 + i < cols) sk_store1(v[i], rsrc, voff + 4 * i, 0, 0);
+    }
+}
 
 __device__ __forceinline__ i32x4 make_rsrc(const void *base, int64_t bytes) {
     union { const void *p; int w[2]; } u;
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
             for (int g = 0; g < KG; ++g) ynx[g] = sk_load4(ry, yoff + g * 32, 0, 0);
         }
     };
-    // dY -> dY * act'(Y) in place, and out to P (whole quads: columns of a straddling quad past K land in the row's padding)
+    // dY -> dY * act'(Y) in place, and out to P (columns < K only)
     auto dact = [&](f32x4 (&dst)[KG], int t) {
         if constexpr (DACT) {
             const int poff = (t * 32 + lr) * ldp4 + 16 * lh;
@@ -141,7 +153,7 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
                                     : p.dact == ACT_TANH ? 1.f - y * y : 1.f;
                     dst[g][i] *= d;
                 }
-                if (8 * g + 4 * lh < p.K) sk_store4(dst[g], rp, poff + g * 32, 0, 0);
+                sk_store_quad(dst[g], rp, poff + g * 32, 8 * g + 4 * lh, p.K);
             }
         }
     };
@@ -199,8 +211,8 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], cur[g][3], acc[nt], 0, 0, 0);
                 if (((nt + g * NT) & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // at most two weight quads in flight
             }
-        // ---- epilogue: lane = row, register 4a + i <-> column nt*32 + 8a + 4h + i; whole quads are stored (the columns of a
-        // straddling quad past N land in the row's padding; rows past M are dropped by the range check)
+        // ---- epilogue: lane = row, register 4a + i <-> column nt*32 + 8a + 4h + i; columns < N only (a quad that straddles N is
+        // stored element by element); rows past M are dropped by the range check
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -217,7 +229,7 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) v[i] = act_apply(p.act, v[i], p.slope);
                 }
-                if (n0 < p.N) sk_store4(v, rc, coff + nt * 128 + a * 32, 0, 0);
+                sk_store_quad(v, rc, coff + nt * 128 + a * 32, n0, p.N);
             }
         if (!more) break;
         tile = ntile;
@@ -252,7 +264,7 @@ static hipError_t launch(const Args &a, hipStream_t st) {
 
 // -> hipErrorNotSupported when the shape is not a skinny one or its rows are not padded to 16 bytes (the caller then takes
 // the LDS-tiled kernel).  Padding contract: lda >= 4 ceil(K/4), ldc >= 4 ceil(N/4), both multiples of 4, bases 16-byte aligned;
-// the columns of C between N and 4 ceil(N/4) are overwritten with garbage.
+// only columns < N of C (and < K of dP) are written: C may be a column slice of a wider buffer.
 extern "C" hipError_t dn_gemm_skinny(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
                                      int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
                                      const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st) {

@@ -133,6 +133,35 @@ def test_gemm_unpadded_rows_take_the_tiled_kernel():
     torch.testing.assert_close(C2.double(), C.double() @ W.double(), rtol=2e-5, atol=2e-4)
 
 
+@pytest.mark.parametrize("N,K", [(90, 64), (90, 90), (30, 17), (61, 64)])
+def test_gemm_into_a_column_slice_leaves_the_neighbours_alone(N, K):
+    """C [M, N] may be a column slice of a wider buffer (include/dagnet_hip.h: explicit row stride).  The skinny
+    kernel stores float4 quads; the quad that straddles column N must not touch columns >= N - nor may the DACT form's dP
+    touch columns >= K.  Sentinels beside the slice must survive every epilogue."""
+    M, ld = 4100, 96
+    g = torch.Generator().manual_seed(N * 131 + K)
+    A = _padded(M, K, g)
+    W = (torch.randn((N, K), generator=g) / K ** 0.5).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = A.double() @ W.double().t()
+    for kw, want in ((dict(), ref), (dict(bias=bias, act=_ops.ACT_LRELU), torch.nn.functional.leaky_relu(ref + bias.double(), 0.01)),
+                     (dict(accumulate=True), ref + 7.0)):
+        big = torch.full((M, ld), 7.0, device=DEV)
+        _ops.gemm(A, W, big[:, :N], **kw)
+        torch.testing.assert_close(big[:, :N].double(), want, rtol=2e-5, atol=2e-5)
+        assert bool((big[:, N:] == 7.0).all()), "columns beside the output slice were overwritten"
+    # DACT: dY, Y [M, K'] with K' = N here (the first operand's width), dP into a slice, C into a slice
+    dY, Y = _padded(M, N, g), _padded(M, N, g)
+    Wt = (torch.randn((N, K), generator=g) / N ** 0.5).to(DEV)          # [K', N'] = [N, K]: C [M, K] = dP Wt
+    bigP = torch.full((M, ld), 5.0, device=DEV)
+    bigC = torch.full((M, ld), 3.0, device=DEV)
+    _ops.gemm_dact(dY, Y, bigP[:, :N], _ops.ACT_RELU, 0.0, Wt, bigC[:, :K])
+    want_p = dY.double() * (Y > 0).double()
+    torch.testing.assert_close(bigP[:, :N].double(), want_p, rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(bigC[:, :K].double(), want_p @ Wt.double(), rtol=2e-5, atol=2e-5)
+    assert bool((bigP[:, N:] == 5.0).all()) and bool((bigC[:, K:] == 3.0).all())
+
+
 @pytest.mark.parametrize("M,N,K", [(4096, 64, 64), (3000, 20, 90), (2500, 90, 64), (2049, 64, 32), (5000, 2, 64), (1000, 64, 64), (2200, 128, 64)])
 @pytest.mark.parametrize("act", [_ops.ACT_LRELU, _ops.ACT_RELU, _ops.ACT_TANH])
 def test_gemm_dact_matches_the_two_steps(M, N, K, act):

@@ -284,3 +284,21 @@ def test_fused_kernels_do_not_change_the_step(kind, kw):
         for name, ref in pg_.items():
             assert float((fg[name] - ref).abs().max()) <= rtol * float(ref.abs().max()) + 1e-7 * gmax, (mask, name)
         torch.testing.assert_close(fh, ph, rtol=10 * rtol, atol=10 * rtol)
+
+
+def test_second_forward_before_backward_is_refused():
+    """the step pool (dagnet_amd/_ops.StepPool) keeps ONE training step's activations; a second train-mode forward
+    overwrites them, so the first graph's backward must raise instead of returning gradients of the wrong activations."""
+    meta, _ = cases.load_golden("train_vrnn_tiny")
+    _, model, _ = cases.build_model(meta)
+    model = model.to(DEV).train()
+    batch, eps = cases.build_train_inputs(meta)
+    obs_rel, eps = batch[2].to(DEV), eps.to(DEV)
+    kld1, nll1, _ = model(obs_rel, eps=eps)
+    kld2, nll2, _ = model(obs_rel * 0.5, eps=eps)
+    with pytest.raises(RuntimeError, match="one training step in flight"):
+        (kld1 + nll1).backward()
+    for p in model.parameters():
+        p.grad = None
+    (kld2 + nll2).backward()                        # the graph of the LAST forward is intact
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())

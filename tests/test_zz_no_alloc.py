@@ -23,10 +23,17 @@ def _both(M, N, ld, accumulate, seed):
     _capi._check(lib.dagnet_op_colsum(M, N, C.c_void_p(X.data_ptr()), ld, C.c_void_p(want.data_ptr()), int(accumulate),
                                       C.c_void_p(ws.data_ptr()), st))
     got = base.clone()
-    before = torch.cuda.memory_allocated(dev)
+    # "allocates nothing" as the DRIVER sees it: torch.cuda.memory_allocated() only counts torch's own allocator and would miss
+    # a hipMalloc inside the library; hipMemGetInfo (torch.cuda.mem_get_info) sees every allocation on the device.  The first
+    # call on a device may load the code object / take the symbol address, so one untimed call comes first.
     _capi._check(lib.dagnet_op_colsum_static(M, N, C.c_void_p(X.data_ptr()), ld, C.c_void_p(got.data_ptr()), int(accumulate), st))
-    assert torch.cuda.memory_allocated(dev) == before
     torch.cuda.synchronize()
+    got.copy_(base)
+    torch.cuda.synchronize()
+    before, before_torch = torch.cuda.mem_get_info(dev)[0], torch.cuda.memory_allocated(dev)
+    _capi._check(lib.dagnet_op_colsum_static(M, N, C.c_void_p(X.data_ptr()), ld, C.c_void_p(got.data_ptr()), int(accumulate), st))
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info(dev)[0] == before and torch.cuda.memory_allocated(dev) == before_torch
     return got.cpu(), want.cpu(), X.cpu().double().sum(0), base.cpu().double()
 
 

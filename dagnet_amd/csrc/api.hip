@@ -28,6 +28,7 @@ extern "C" hipError_t dn_launch_best_of_k(const int32_t *scene_ptr, int S, int N
                                           const float *start, const float *gt, float *ade, float *fde, float *scene_best,
                                           double *sums, hipStream_t st);
 extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *w, const V2Run *r, hipStream_t st);
+extern "C" hipError_t dn_launch_rollout_v2_bf3(int model, int n_layers, int z_dim, int graph, const V2Weights *w, const V2Run *r, hipStream_t st);
 extern "C" int dn_v2_has(int model, int n_layers, int z_dim, int graph);
 extern "C" hipError_t dn_launch_forward_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *w, const V2Run *r, hipStream_t st);
 extern "C" hipError_t dn_launch_loss_finalize(int n_tiles, int N, const double *part, double *losses, hipStream_t st);
@@ -96,9 +97,11 @@ struct dagnet_model {
     size_t wp_floats = 0;
     int device = 0;
     bool v2 = false;            // the register-resident kernel (rollout_v2.hip) covers this model
-    V2Weights w2;               // absolute offsets into d_wp (read by model 3 only: wide goal head)
-    V2Weights *d_w2 = nullptr;  // device copy of w2
-    int v2_base = 0;            // start of the v2 region in d_wp: the v2 kernels use compile-time offsets relative to it
+    // two v2 regions: [0] fp32 MFMA blocks (the teacher-forced kernels, and the rollout when split-bf16 is switched off),
+    // [1] split-bf16 blocks (the rollout kernels' default)
+    V2Weights w2[2];            // absolute offsets into d_wp (read by model 3 only: wide goal head)
+    V2Weights *d_w2[2] = {nullptr, nullptr};  // device copies of w2
+    int v2_base[2] = {0, 0};    // start of the v2 regions in d_wp: the v2 kernels use compile-time offsets relative to them
     // wide goal head (wide_head.hip) + register-resident kernel model 3 for the rest of the step
     bool wide = false;
     WideWeights ww;
@@ -208,6 +211,44 @@ struct Packer {
                         }
         return off;
     }
+    // The same blocks for the bf16 matrix pipe (params_v2.h, v2_common.h mm<..., BF = true>): every weight as three bf16 terms by
+    // truncation (8 + 8 + 8 significant bits: hi + mid + lo is the weight exactly); a half block (output tile nt, input tile kt,
+    // k-half p) = [term][lane 64][8 bf16], slot s of lane (n, h) = W[nt*32+n][kt*32 + 8*(2p + s/4) + 4h + s%4]; 768 dwords.
+    // kt_major: half blocks ordered [kt][p][nt] (dense layers: half an input tile is split once for all output tiles),
+    // else [nt][kt][p] (one output tile per product).
+    bool bf = false;            // v2 region being packed: chain_v2() emits split-bf16 blocks
+    int chain3(const WFn &W, int N, int K, bool kt_major) {
+        const int nt = (N + 31) / 32, kt = (K + 31) / 32;
+        const int off = align();
+        buf.resize(off + (size_t)nt * kt * V2_BLOCK_BF3, 0.f);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(buf.data() + off);
+        auto trunc_bf16 = [](float v) -> uint32_t {
+            uint32_t u;
+            memcpy(&u, &v, 4);
+            return u & 0xffff0000u;
+        };
+        for (int a = 0; a < nt; ++a)
+            for (int b = 0; b < kt; ++b)
+                for (int p = 0; p < 2; ++p) {
+                    const size_t half = kt_major ? ((size_t)b * 2 + p) * nt + a : ((size_t)a * kt + b) * 2 + p;
+                    for (int l = 0; l < 64; ++l)
+                        for (int sl = 0; sl < 8; ++sl) {
+                            const int n = a * 32 + (l & 31), k = b * 32 + 8 * (2 * p + sl / 4) + 4 * (l >> 5) + sl % 4;
+                            float v = (n < N && k < K) ? W(n, k) : 0.f;
+                            for (int t = 0; t < 3; ++t) {
+                                const uint32_t hi = trunc_bf16(v);
+                                float hf;
+                                memcpy(&hf, &hi, 4);
+                                v -= hf;                                   // exact: the top 8 significant bits removed
+                                uint32_t &word = dst[half * V2_HALF_BF3 + ((size_t)t * 64 + l) * 4 + sl / 2];
+                                word = (sl & 1) ? ((word & 0x0000ffffu) | hi) : ((word & 0xffff0000u) | (hi >> 16));
+                            }
+                        }
+                }
+        return off;
+    }
+    // the v2 regions' dense segments: fp32 chain order or split-bf16 blocks, as the region being packed says
+    int chain_v2(const WFn &W, int N, int K, bool kt_major) { return bf ? chain3(W, N, K, kt_major) : chain(W, N, K); }
     // plain row-major [N][ld] (ld >= K, zero padded): operands of the batched GEMMs (gemm_f32.hip)
     int rowmajor(const WFn &W, int N, int K, int ld) {
         const int off = align();
@@ -439,7 +480,7 @@ V2Lin v2_linear(Packer &pk, const std::string &name, int N, int Ktot, std::vecto
     for (size_t s = 0; s < segs.size(); ++s) {
         const int c0 = segs[s].col0;
         const int Ks = segs[s].K;
-        L.w[s] = pk.chain([=](int n, int k) { return (n < N && k < Ks) ? sc * w[(size_t)n * Ktot + c0 + k] : 0.f; }, Np, std::max(Ks, segs[s].kpad));
+        L.w[s] = pk.chain_v2([=](int n, int k) { return (n < N && k < Ks) ? sc * w[(size_t)n * Ktot + c0 + k] : 0.f; }, Np, std::max(Ks, segs[s].kpad), true);
     }
     if (logits) L.bias = pk.vec([=](int n) { return n < N ? sc * b[n] : -INFINITY; }, pad32(Np), pad32(Np));
     else L.bias = pk.vec([=](int n) { return b[n]; }, N, pad32(Np));
@@ -456,7 +497,7 @@ V2Lin v2_pair(Packer &pk, const std::string &a, const std::string &b, int Z, int
     const Tensor *Ba = pk.get(a + ".bias", {Z}), *Bb = pk.get(b + ".bias", {Z});
     if (!Wa || !Wb || !Ba || !Bb) return L;
     const float *wa = Wa->p, *wb = Wb->p, *ba = Ba->p, *bb = Bb->p;
-    L.w[0] = pk.chain([=](int n, int k) { return n < Z ? wa[(size_t)n * K + k] : wb[(size_t)(n - Z) * K + k]; }, 2 * Z, K);
+    L.w[0] = pk.chain_v2([=](int n, int k) { return n < Z ? wa[(size_t)n * K + k] : wb[(size_t)(n - Z) * K + k]; }, 2 * Z, K, true);
     L.bias = pk.vec([=](int n) { return n < Z ? ba[n] : bb[n - Z]; }, 2 * Z, pad32(2 * Z));
     return L;
 }
@@ -481,7 +522,7 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     if (!Wo || !ao) return g;
     const float *wo = Wo->p, *aop = ao->p;
     const int ninp = std::max(nin, pad), noutp = std::max(nout, pad);
-    g.heads = pk.chain([=](int n, int k) { return k < nin ? Wh[n / F][(size_t)k * F + (n % F)] : 0.f; }, P * F, ninp);
+    g.heads = pk.chain_v2([=](int n, int k) { return k < nin ? Wh[n / F][(size_t)k * F + (n % F)] : 0.f; }, P * F, ninp, false);
     // attention vectors of the heads for the per-lane logit reduction (v2_common.h gat<>): entry 8p+f = a_p[f] (source half)
     // and 32 + 8p+f = a_p[F+f] (destination half), in the log2 domain: the kernels' softmax is exp2(e - max)
     g.fold = pk.vec([=](int i) { const int q = i & 31; return (float)((double)ah[q / F][(i >> 5) * F + (q % F)] * kLog2e); }, 64, 64);
@@ -491,9 +532,9 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     const float *gp = ga->p, *bp = be->p, *mp = mu->p, *vp = var->p;
     // eval-mode BatchNorm y = x * scale + shift and the factor 2 log2(e) of the kernels' tanh2() (v2_common.h): the scale
     // goes into the out_att weights (the attention sums over rows, the scale is per feature), the shift into g.bn
-    g.out = pk.chain(
+    g.out = pk.chain_v2(
         [=](int n, int k) { return n < nout ? (float)(kTanhScale * (gp[n] / sqrtf(vp[n] + 1e-5f)) * wo[(size_t)k * nout + n]) : 0.f; },
-        noutp, P * F);
+        noutp, P * F, false);
     // a_out . (x2 W_out) == x2 . (W_out a_out): the out head's two logit dot products over its 32 input features
     g.fold_out = pk.vec(
         [=](int i) {
@@ -527,8 +568,8 @@ V2Gat v2_gcn(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     if (pk.has(prefix + ".gc1.bias")) { const Tensor *b = pk.get(prefix + ".gc1.bias", {F}); if (b) b1 = b->p; }
     if (pk.has(prefix + ".gc2.bias")) { const Tensor *b = pk.get(prefix + ".gc2.bias", {nout}); if (b) b2 = b->p; }
     const int ninp = std::max(nin, pad), noutp = std::max(nout, pad);
-    g.heads = pk.chain([=](int n, int k) { return k < nin ? w1[(size_t)k * F + n] : 0.f; }, F, ninp);
-    g.out = pk.chain([=](int n, int k) { return n < nout ? w2[(size_t)k * nout + n] : 0.f; }, noutp, F);
+    g.heads = pk.chain_v2([=](int n, int k) { return k < nin ? w1[(size_t)k * F + n] : 0.f; }, F, ninp, false);
+    g.out = pk.chain_v2([=](int n, int k) { return n < nout ? w2[(size_t)k * nout + n] : 0.f; }, noutp, F, false);
     auto fold = [&](const std::string &bn, int n, const float *bias, int ld, double act) {
         const Tensor *ga = pk.get(bn + ".weight", {n}), *be = pk.get(bn + ".bias", {n});
         const Tensor *mu = pk.get(bn + ".running_mean", {n}), *var = pk.get(bn + ".running_var", {n});
@@ -566,8 +607,8 @@ V2Gru v2_gru(Packer &pk, int l, int R, int H) {
         L.gather = -1;
         int s = 0;
         const double a = gate == 2 ? kTanhScale : kSigmScale;
-        if (with_x) L.w[s++] = pk.chain([=](int n, int k) { return (float)(a * wi[(size_t)(gate * R + n) * Kin + k]); }, R, Kin);
-        if (with_h) L.w[s++] = pk.chain([=](int n, int k) { return (float)(a * wh[(size_t)(gate * R + n) * R + k]); }, R, R);
+        if (with_x) L.w[s++] = pk.chain_v2([=](int n, int k) { return (float)(a * wi[(size_t)(gate * R + n) * Kin + k]); }, R, Kin, false);
+        if (with_h) L.w[s++] = pk.chain_v2([=](int n, int k) { return (float)(a * wh[(size_t)(gate * R + n) * R + k]); }, R, R, false);
         L.bias = pk.vec([=](int n) { return (float)(a * ((with_x ? bi[gate * R + n] : 0.f) + (with_h ? bh[gate * R + n] : 0.f))); }, R, pad32(R));
     };
     mk(g.r, 0, true, true);
@@ -714,8 +755,8 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
 // The packer's table against the compile-time layout of the instantiation that will run (params_v2.h v2_layout):
 // every offset the layout marks as used must equal base + the layout's relative offset.  Returns a description of the
 // first difference, or an empty string.
-std::string v2_check_layout(const V2Weights &W, int base, int total, int model_code, int nl, int zd, int gm) {
-    const V2Layout L = v2_layout(model_code, nl, zd, gm);
+std::string v2_check_layout(const V2Weights &W, int base, int total, int model_code, int nl, int zd, int gm, int bf) {
+    const V2Layout L = v2_layout(model_code, nl, zd, gm, bf);
     const int32_t *a = reinterpret_cast<const int32_t *>(&W), *o = reinterpret_cast<const int32_t *>(&L.off),
                   *u = reinterpret_cast<const int32_t *>(&L.used);
     for (size_t i = 0; i < sizeof(V2Weights) / sizeof(int32_t); ++i)
@@ -823,16 +864,20 @@ extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor
     m->v2 = v2_eligible(c);
     m->wide = !m->v2 && wide_eligible(c) && !getenv("DAGNET_NO_WIDE");
     if ((m->v2 || m->wide) && pk.missing.empty()) {
-        m->v2_base = pk.align();
-        v2_pack(pk, c, m->w2, m->wide);
-        if (pk.missing.empty() && !m->wide) {      // (model 3 reads the table: its one-hot tables have g_dim rows)
-            const int code = dag && Dd > 32 ? 4 : c.model;
-            const std::string bad = v2_check_layout(m->w2, m->v2_base, pk.align() - m->v2_base, code, c.n_layers, c.z_dim,
-                                                    c.graph_model == DAGNET_GRAPH_GCN ? 2 : 1);
-            if (!bad.empty()) {
-                const int rc = fail(DAGNET_ERR_INVALID, "internal error, %s", bad.c_str());
-                delete m;
-                return rc;
+        for (int bf = 0; bf < 2; ++bf) {
+            m->v2_base[bf] = pk.align();
+            pk.bf = bf != 0;
+            v2_pack(pk, c, m->w2[bf], m->wide);
+            pk.bf = false;
+            if (pk.missing.empty() && !m->wide) {      // (model 3 reads the table: its one-hot tables have g_dim rows)
+                const int code = dag && Dd > 32 ? 4 : c.model;
+                const std::string bad = v2_check_layout(m->w2[bf], m->v2_base[bf], pk.align() - m->v2_base[bf], code, c.n_layers, c.z_dim,
+                                                        c.graph_model == DAGNET_GRAPH_GCN ? 2 : 1, bf);
+                if (!bad.empty()) {
+                    const int rc = fail(DAGNET_ERR_INVALID, "internal error, %s", bad.c_str());
+                    delete m;
+                    return rc;
+                }
             }
         }
         if (m->wide) wide_pack(pk, c, m->ww);
@@ -847,13 +892,14 @@ extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor
     hipError_t e = hipGetDevice(&m->device);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&m->d_wp), m->wp_floats * sizeof(float));
     if (e == hipSuccess) e = hipMemcpy(m->d_wp, pk.buf.data(), m->wp_floats * sizeof(float), hipMemcpyHostToDevice);
-    if (e == hipSuccess && (m->v2 || m->wide)) {
-        e = hipMalloc(reinterpret_cast<void **>(&m->d_w2), sizeof(V2Weights));
-        if (e == hipSuccess) e = hipMemcpy(m->d_w2, &m->w2, sizeof(V2Weights), hipMemcpyHostToDevice);
+    for (int bf = 0; bf < 2 && e == hipSuccess && (m->v2 || m->wide); ++bf) {
+        e = hipMalloc(reinterpret_cast<void **>(&m->d_w2[bf]), sizeof(V2Weights));
+        if (e == hipSuccess) e = hipMemcpy(m->d_w2[bf], &m->w2[bf], sizeof(V2Weights), hipMemcpyHostToDevice);
     }
     if (e != hipSuccess) {
         if (m->d_wp) (void)hipFree(m->d_wp);
-        if (m->d_w2) (void)hipFree(m->d_w2);
+        for (int bf = 0; bf < 2; ++bf)
+            if (m->d_w2[bf]) (void)hipFree(m->d_w2[bf]);
         delete m;
         return fail(DAGNET_ERR_HIP, "weight upload failed: %s", hipGetErrorString(e));
     }
@@ -864,7 +910,8 @@ extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor
 extern "C" void dagnet_model_destroy(dagnet_model *m) {
     if (!m) return;
     if (m->d_wp) (void)hipFree(m->d_wp);
-    if (m->d_w2) (void)hipFree(m->d_w2);
+    for (int bf = 0; bf < 2; ++bf)
+        if (m->d_w2[bf]) (void)hipFree(m->d_w2[bf]);
     delete m;
 }
 
@@ -1203,14 +1250,20 @@ static DnNanDst nan_dst(void *p, int64_t plane_stride, int64_t planes, int cols)
     return DnNanDst{static_cast<uint32_t *>(p), plane_stride, planes, cols};
 }
 
+// The rollout kernels' dense products: split bf16 (three bf16 terms per fp32 value on the bf16 matrix pipe) unless switched off -
+// DAGNET_NO_BF16X3 in the environment or bit 3 of dagnet_op_set_fused, the switch of the wide GEMM's split products.
+static int fused_mask();
+static int rollout_bf3() { return (fused_mask() >> 3) & 1; }
+
 static int sample_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, const float *d_h0, const float *d_x0,
                        const int32_t *d_g0, const float *d_eps, const float *d_q, const int32_t *d_force_goals, uint64_t seed,
                        float *d_out, int32_t *d_out_goals, void *stream) {
     if (!m || !p) return fail(DAGNET_ERR_INVALID, "null argument");
     if (m->v2 && p->n_tiles2 > 0 && !getenv("DAGNET_FORCE_GENERIC")) {
+        const int bf = rollout_bf3();
         V2Run r;
         memset(&r, 0, sizeof(r));
-        r.wp = m->d_wp + m->v2_base;      // rollout_v2: compile-time offsets relative to the v2 region
+        r.wp = m->d_wp + m->v2_base[bf];      // rollout_v2: compile-time offsets relative to the v2 region
         r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
         r.S = p->S; r.N = p->N; r.K = p->K; r.T = T; r.n_tiles = p->n_tiles2;
         r.G = m->dims.G; r.D = m->dims.D; r.adj_type = m->dims.adj_type; r.top_k = m->dims.knn_k;
@@ -1221,7 +1274,8 @@ static int sample_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, c
         if (getenv("DAGNET_V2_DUMP")) r.dbg = reinterpret_cast<float *>(g_prof);
         else r.prof = g_prof;
 #endif
-        HIP_TRY(dn_launch_rollout_v2(v2_model_code(m), m->dims.L, m->dims.Z, m->dims.graph, m->d_w2, &r, static_cast<hipStream_t>(stream)));
+        HIP_TRY((bf ? dn_launch_rollout_v2_bf3 : dn_launch_rollout_v2)(v2_model_code(m), m->dims.L, m->dims.Z, m->dims.graph, m->d_w2[bf], &r,
+                                                                       static_cast<hipStream_t>(stream)));
         return DAGNET_OK;
     }
     if (m->wide && p->wide && !getenv("DAGNET_FORCE_GENERIC")) {
@@ -1229,6 +1283,7 @@ static int sample_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, c
         // register-resident kernel (model 3) with the drawn goals; state lives in the plan's workspace
         hipStream_t st = static_cast<hipStream_t>(stream);
         const DnDims &D = m->dims;
+        const int bf = rollout_bf3();
         HIP_TRY(dn_wide_init_state(p->N, p->K, D.L, D.R, D.G, d_h0, d_x0, d_g0, p->wb.h, p->wb.pos, p->wb.goal, st));
         WideStep ws;
         memset(&ws, 0, sizeof(ws));
@@ -1250,7 +1305,7 @@ static int sample_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, c
             ws.t = t;
             HIP_TRY(dn_wide_goal_head(&ws, st));
             r.t_begin = t; r.t_end = t + 1;
-            HIP_TRY(dn_launch_rollout_v2(3, D.L, D.Z, D.graph, m->d_w2, &r, st));
+            HIP_TRY((bf ? dn_launch_rollout_v2_bf3 : dn_launch_rollout_v2)(3, D.L, D.Z, D.graph, m->d_w2[bf], &r, st));
         }
         return DAGNET_OK;
     }
@@ -1356,7 +1411,7 @@ static int forward_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, 
             ws.ext_adj = P.r.adj + (int64_t)t * P.r.adj_tstride;
             HIP_TRY(dn_wide_goal_head(&ws, st));
             r.t_begin = t; r.t_end = t + 1;
-            HIP_TRY(dn_launch_forward_v2(3, D.L, D.Z, D.graph, m->d_w2, &r, st));
+            HIP_TRY(dn_launch_forward_v2(3, D.L, D.Z, D.graph, m->d_w2[0], &r, st));
         }
         HIP_TRY(dn_wide_ce_finish(N, ce_acc, p->d_loss_part, st));
         HIP_TRY(dn_launch_loss_finalize(p->n_tiles2, p->N, p->d_loss_part, d_losses, st));
@@ -1366,7 +1421,7 @@ static int forward_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, 
         // register-resident teacher-forced pass (forward_v2.hip); GAT consumes only the adjacency's support
         V2Run r;
         memset(&r, 0, sizeof(r));
-        r.wp = m->d_wp + m->v2_base;      // compile-time offsets relative to the v2 region
+        r.wp = m->d_wp + m->v2_base[0];   // compile-time offsets relative to the (fp32) v2 region
         r.scene_ptr = p->d_scene_ptr; r.tile_u0 = p->d_tile2_u0; r.tile_nu = p->d_tile2_nu;
         r.S = p->S; r.N = p->N; r.K = 1; r.T = T; r.n_tiles = p->n_tiles2;
         r.G = m->dims.G; r.D = m->dims.D; r.adj_type = m->dims.adj_type; r.top_k = m->dims.knn_k; r.alpha = m->dims.alpha; r.sigma = m->dims.sigma;
@@ -1374,7 +1429,7 @@ static int forward_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, 
         r.traj = d_traj; r.traj_rel = d_traj_rel; r.goals = d_goals;
         r.adj = P.r.adj; r.adj_ld = P.r.adj_ld; r.adj_tstride = P.r.adj_tstride; r.adj_off = P.r.adj_off;
         r.loss_part = p->d_loss_part;
-        HIP_TRY(dn_launch_forward_v2(v2_model_code(m), m->dims.L, m->dims.Z, m->dims.graph, m->d_w2, &r, st));
+        HIP_TRY(dn_launch_forward_v2(v2_model_code(m), m->dims.L, m->dims.Z, m->dims.graph, m->d_w2[0], &r, st));
         HIP_TRY(dn_launch_loss_finalize(p->n_tiles2, p->N, p->d_loss_part, d_losses, st));
         return DAGNET_OK;
     }

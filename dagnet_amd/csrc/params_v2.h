@@ -58,15 +58,26 @@ struct V2Weights {
 // ---------------------------------------------------------------------------------------------
 #define V2_GT 3     // goal tiles (g_dim <= 96)
 
+// Split-bf16 packing (bf = 1; v2_common.h mm<..., BF = true>, api.hip Packer::chain3): every fp32 weight is three bf16 terms
+// (8 + 8 + 8 significant bits by truncation: hi + mid + lo IS the weight), and a 32 x 32 block is
+//     two half blocks (k-half p = 0, 1) of [term 0..2][lane 64] 8 x bf16 = W_term[32*nt + n][32*kt + 8*(2p + s/4) + 4*h + s%4], s = 0..7
+// - the operand of v_mfma_f32_32x32x16_bf16 whose 8 k-slots of lane half h are registers 8p .. 8p+7 of an input tile -
+// i.e. 2 x 768 dwords where the fp32 block has 1024.  Dense layers are streamed [kt][p][nt] (half an input tile is split once
+// and feeds all output tiles); GRU gates and the graph layers' per-tile products are one output tile per call: [nt][kt][p].
+#define V2_BLOCK_F32 1024
+#define V2_BLOCK_BF3 1536
+#define V2_HALF_BF3 768
+
 struct V2Layout {
     V2Weights off;      // relative float offsets
     V2Weights used;     // 1 where `off` holds an offset this instantiation packs
     int32_t total;      // floats in the v2 region
 };
 
-constexpr V2Layout v2_layout(int model, int nl, int zd, int gm) {
+constexpr V2Layout v2_layout(int model, int nl, int zd, int gm, int bf = 0) {
     V2Layout L{};
     int32_t cur = 0;
+    const int BS = bf ? V2_BLOCK_BF3 : V2_BLOCK_F32;
     const bool dag = model >= 2, graph = model != 0, head = model == 2 || model == 4;
     const int DT = (model == 3 || model == 4) ? 2 : 1, GT = V2_GT, GP = V2_GT * 32;
     const int zt2 = (2 * zd + 31) / 32;
@@ -80,9 +91,9 @@ constexpr V2Layout v2_layout(int model, int nl, int zd, int gm) {
     auto lin = [&](V2Lin &o, V2Lin &u, int nt, int k0, int k1, int k2, bool gather) {
         o.bias = -1;
         o.gather = -1;
-        if (k0) take(o.w[0], u.w[0], nt * k0 * 1024);
-        if (k1) take(o.w[1], u.w[1], nt * k1 * 1024);
-        if (k2) take(o.w[2], u.w[2], nt * k2 * 1024);
+        if (k0) take(o.w[0], u.w[0], nt * k0 * BS);
+        if (k1) take(o.w[1], u.w[1], nt * k1 * BS);
+        if (k2) take(o.w[2], u.w[2], nt * k2 * BS);
         take(o.bias, u.bias, nt * 32);
         if (gather) take(o.gather, u.gather, GP * nt * 32);
     };
@@ -92,14 +103,14 @@ constexpr V2Layout v2_layout(int model, int nl, int zd, int gm) {
     };
     auto graphnet = [&](V2Gat &o, V2Gat &u, int kt, int nt) {
         if (gm == 2) {      // GCN: heads = W1, out = W2, fold / bn = folded scale | shift of the two layers
-            take(o.heads, u.heads, kt * 1024);
-            take(o.out, u.out, nt * 1024);
+            take(o.heads, u.heads, kt * BS);
+            take(o.out, u.out, nt * BS);
             take(o.fold, u.fold, 64);
             take(o.bn, u.bn, 2 * nt * 32);
         } else {
-            take(o.heads, u.heads, kt * 1024);
+            take(o.heads, u.heads, kt * BS);
             take(o.fold, u.fold, 64);
-            take(o.out, u.out, nt * 1024);
+            take(o.out, u.out, nt * BS);
             take(o.fold_out, u.fold_out, 64);
             take(o.bn, u.bn, 2 * nt * 32);
         }

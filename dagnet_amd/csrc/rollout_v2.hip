@@ -27,12 +27,14 @@ namespace v2 {
 // step is read from the per-sample goal state; state is per (sample, row) and written back after the last step).
 // NL: GRU layers.  ZT: 32 -> z_dim 32, 16 -> z_dim 16.
 // GM: 1 = GAT (4 heads x 8), 2 = GCN (graph_hid <= 32).
-template <int MODEL, int NL, int ZD, int GM>
+// BF: dense products on the bf16 matrix pipe (three bf16 terms per fp32 value, v2_common.h mm<..., BF>); weights from the
+// split-bf16 region of the model (params_v2.h).
+template <int MODEL, int NL, int ZD, int GM, bool BF>
 __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
     // segment offsets are compile-time constants of the instantiation (params_v2.h v2_layout; checked against the packer's
     // table when the model is created): immediates, no table loads on the critical path, no SGPRs held for them
     // (model 3 keeps the packer's table: its one-hot tables have g_dim rows, in the hundreds)
-    static constexpr V2Layout LO = v2_layout(MODEL, NL, ZD, GM);
+    static constexpr V2Layout LO = v2_layout(MODEL, NL, ZD, GM, BF);
     const V2Weights &W = MODEL == 3 ? *Wp : LO.off;
     __shared__ float xch[32 * 4 + 64];
     __shared__ float gfold[GM == 1 ? 2 * GAT_FOLD_FLOATS : 1];      // attention vectors of the hidden / goal GAT (v2_common.h gat_fold_to_lds)
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     if constexpr (GRAPH && GM == 1) gat_fold_to_lds(gfold, wp, W.g_hid, lane);
     if constexpr (HEAD && GM == 1) gat_fold_to_lds(gfold + GAT_FOLD_FLOATS, wp, W.g_goal, lane);
     const int first_off = HEAD ? W.dec_goal0.w[0] : W.prior0.w[0];
-    WBlk pre = wload(wp, first_off, lane);
+    WBlk pre = wload<BF>(wp, first_off, lane);
 #ifdef DN_PROFILE
     long long pstamp = clock64();
 #define PH(i)                                                                     \
@@ -258,8 +260,8 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             // ---------------------------------------------------------------- goal head
             T16 tg[2];
             start<2>(tg, wp, W.dec_goal0, gi, lh);
-            pre = mm<2, DT, false>(tg, wp, W.dec_goal0.w[0], d, lane, pre, W.dec_goal0.w[1]);
-            pre = mm<2, 2, false>(tg, wp, W.dec_goal0.w[1], h[NL - 1], lane, pre, W.dec_goal2.w[0]);
+            pre = mm<2, DT, false, BF>(tg, wp, W.dec_goal0.w[0], d, lane, pre, W.dec_goal0.w[1]);
+            pre = mm<2, 2, false, BF>(tg, wp, W.dec_goal0.w[1], h[NL - 1], lane, pre, W.dec_goal2.w[0]);
             activate<2, 2>(tg);
             // the top-layer hidden state is not read again until the prior: park it as well
 #pragma unroll
@@ -268,7 +270,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
                 for (int r = 0; r < 16; ++r) stash[(nt * 16 + r) * 64 + lane] = h[NL - 1][nt][r];
             T16 decg[GT];
             start<GT>(decg, wp, W.dec_goal2, 0, lh);
-            pre = mm<GT, 2, false>(decg, wp, W.dec_goal2.w[0], tg, lane, pre, W.lg_goals.w[0]);
+            pre = mm<GT, 2, false, BF>(decg, wp, W.dec_goal2.w[0], tg, lane, pre, W.lg_goals.w[0]);
             activate<0, GT>(decg);
             softmax_feat<GT>(decg);
             PH(1);
@@ -276,12 +278,12 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
             // once the graph has consumed it (peak registers: gc + gg instead of dec_g + gg + gc)
             T16 gc[GT];
             start<GT>(gc, wp, W.lg_goals, 0, lh);
-            pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.g_goal.heads);
+            pre = mm<GT, GT, false, BF>(gc, wp, W.lg_goals.w[0], decg, lane, pre, W.g_goal.heads);
             T16 gg[GT];
-            if constexpr (GM == 2) pre = gcn<GT, GT>(decg, gg, wp, W.g_goal, adjval, lane, pre, W.lg_goals.w[1]);
-            else pre = gat<GT, GT>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, gfold + GAT_FOLD_FLOATS, lane, pre, W.lg_goals.w[1], [&](int i) { PH(i); });
+            if constexpr (GM == 2) pre = gcn<GT, GT, BF>(decg, gg, wp, W.g_goal, adjval, lane, pre, W.lg_goals.w[1]);
+            else pre = gat<GT, GT, BF>(decg, gg, wp, W.g_goal, amask, R.alpha, xch, gfold + GAT_FOLD_FLOATS, lane, pre, W.lg_goals.w[1], [&](int i) { PH(i); });
             PH(2);
-            pre = mm<GT, GT, false>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.prior0.w[0]);
+            pre = mm<GT, GT, false, BF>(gc, wp, W.lg_goals.w[1], gg, lane, pre, W.prior0.w[0]);
             activate<0, GT>(gc);
             // softmax left unnormalised: gc = exp2(logit - max), p = gc * inv
             const float pscale = softmax_feat_unnorm<GT>(gc) * 1.44269504088896340736f;
@@ -341,16 +343,16 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         T16 ta[2], tb[2];
         DBG(7, h[NL - 1], 2);
         start<2>(ta, wp, W.prior0, gi, lh);
-        pre = mm<2, 2, false>(ta, wp, W.prior0.w[0], h[NL - 1], lane, pre, W.prior2.w[0]);
+        pre = mm<2, 2, false, BF>(ta, wp, W.prior0.w[0], h[NL - 1], lane, pre, W.prior2.w[0]);
         activate<1, 2>(ta);
         DBG(0, ta, 2);
         start<2>(tb, wp, W.prior2, 0, lh);
-        pre = mm<2, 2, false>(tb, wp, W.prior2.w[0], ta, lane, pre, W.prior_ml.w[0]);
+        pre = mm<2, 2, false, BF>(tb, wp, W.prior2.w[0], ta, lane, pre, W.prior_ml.w[0]);
         activate<1, 2>(tb);
         constexpr int MLT = ZD == 32 ? 2 : 1;      // [mean ; logvar] = 2*z_dim features
         T16 ml[MLT];
         start<MLT>(ml, wp, W.prior_ml, 0, lh);
-        pre = mm<MLT, 2, false>(ml, wp, W.prior_ml.w[0], tb, lane, pre, W.phi_z0.w[0]);
+        pre = mm<MLT, 2, false, BF>(ml, wp, W.prior_ml.w[0], tb, lane, pre, W.phi_z0.w[0]);
         activate<0, MLT>(ml);
         DBG(1, tb, 2);
         DBG(2, ml, MLT);
@@ -391,27 +393,27 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         PH(5);
         // -------------------------------------------------------------------- phi_z, decoder
         start<2>(ta, wp, W.phi_z0, 0, lh);
-        pre = mm<2, 1, false>(ta, wp, W.phi_z0.w[0], z, lane, pre, W.phi_z2.w[0]);
+        pre = mm<2, 1, false, BF>(ta, wp, W.phi_z0.w[0], z, lane, pre, W.phi_z2.w[0]);
         activate<1, 2>(ta);
         T16 pz[2];
         start<2>(pz, wp, W.phi_z2, 0, lh);
-        pre = mm<2, 2, false>(pz, wp, W.phi_z2.w[0], ta, lane, pre, W.dec0.w[0]);
+        pre = mm<2, 2, false, BF>(pz, wp, W.phi_z2.w[0], ta, lane, pre, W.dec0.w[0]);
         activate<1, 2>(pz);
         DBG(4, pz, 2);
         start<2>(ta, wp, W.dec0, gi, lh);
         if (DAG) {
             // rebuilt from the positions in LDS (unchanged since the start of the step) rather than kept live
             build_disposition();
-            pre = mm<2, DT, false>(ta, wp, W.dec0.w[0], d, lane, pre, W.dec0.w[1]);
-            pre = mm<2, 2, false>(ta, wp, W.dec0.w[1], pz, lane, pre, W.dec0.w[2]);
-            pre = mm<2, 2, false>(ta, wp, W.dec0.w[2], h[NL - 1], lane, pre, W.dec2.w[0]);
+            pre = mm<2, DT, false, BF>(ta, wp, W.dec0.w[0], d, lane, pre, W.dec0.w[1]);
+            pre = mm<2, 2, false, BF>(ta, wp, W.dec0.w[1], pz, lane, pre, W.dec0.w[2]);
+            pre = mm<2, 2, false, BF>(ta, wp, W.dec0.w[2], h[NL - 1], lane, pre, W.dec2.w[0]);
         } else {
-            pre = mm<2, 2, false>(ta, wp, W.dec0.w[0], pz, lane, pre, W.dec0.w[1]);
-            pre = mm<2, 2, false>(ta, wp, W.dec0.w[1], h[NL - 1], lane, pre, W.dec2.w[0]);
+            pre = mm<2, 2, false, BF>(ta, wp, W.dec0.w[0], pz, lane, pre, W.dec0.w[1]);
+            pre = mm<2, 2, false, BF>(ta, wp, W.dec0.w[1], h[NL - 1], lane, pre, W.dec2.w[0]);
         }
         activate<1, 2>(ta);
         start<2>(tb, wp, W.dec2, 0, lh);
-        pre = mm<2, 2, false>(tb, wp, W.dec2.w[0], ta, lane, pre, W.phi_x2.w[0]);
+        pre = mm<2, 2, false, BF>(tb, wp, W.dec2.w[0], ta, lane, pre, W.phi_x2.w[0]);
         activate<1, 2>(tb);
         DBG(5, ta, 2);
         DBG(6, tb, 2);
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         {
             T16 px[2];
             start<2>(px, wp, W.phi_x2, 0, lh);
-            pre = mm<2, 2, false>(px, wp, W.phi_x2.w[0], ta, lane, pre, W.gru[0].nh.w[0]);
+            pre = mm<2, 2, false, BF>(px, wp, W.phi_x2.w[0], ta, lane, pre, W.gru[0].nh.w[0]);
             activate<1, 2>(px);
             xin[0] = px[0]; xin[1] = px[1]; xin[2] = pz[0]; xin[3] = pz[1];
         }
@@ -471,13 +473,13 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stash[(nt * 16 + r) * 64 + lane] = h[1][nt][r];
         }
-        pre = gru<4, true>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? W.gru[1].nh.w[0] : after_gru, gbias);
+        pre = gru<4, true, BF>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? W.gru[1].nh.w[0] : after_gru, gbias);
         if constexpr (NL == 2) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[1][nt][r] = stash[(nt * 16 + r) * 64 + lane];
-            pre = gru<2, true>(h[0], h[1], wp, W.gru[1], lane, pre, after_gru, gbias + GRU_BIAS_FLOATS);
+            pre = gru<2, true, BF>(h[0], h[1], wp, W.gru[1], lane, pre, after_gru, gbias + GRU_BIAS_FLOATS);
         }
         PH(8);
         // -------------------------------------------------------------------- graph refinement of h[-1]
@@ -488,11 +490,11 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         }
         if (GRAPH) {
             T16 hg[2];
-            if constexpr (GM == 2) pre = gcn<2, 2>(h[NL - 1], hg, wp, W.g_hid, adjval, lane, pre, W.blend.w[0]);
-            else pre = gat<2, 2>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, gfold, lane, pre, W.blend.w[0]);
+            if constexpr (GM == 2) pre = gcn<2, 2, BF>(h[NL - 1], hg, wp, W.g_hid, adjval, lane, pre, W.blend.w[0]);
+            else pre = gat<2, 2, BF>(h[NL - 1], hg, wp, W.g_hid, amask, R.alpha, xch, gfold, lane, pre, W.blend.w[0]);
             start<2>(ta, wp, W.blend, 0, lh);
-            pre = mm<2, 2, false>(ta, wp, W.blend.w[0], hg, lane, pre, W.blend.w[1]);
-            pre = mm<2, 2, false>(ta, wp, W.blend.w[1], h[NL - 1], lane, pre, first_off);
+            pre = mm<2, 2, false, BF>(ta, wp, W.blend.w[0], hg, lane, pre, W.blend.w[1]);
+            pre = mm<2, 2, false, BF>(ta, wp, W.blend.w[1], h[NL - 1], lane, pre, first_off);
             activate<0, 2>(ta);
             h[NL - 1][0] = ta[0];
             h[NL - 1][1] = ta[1];
@@ -520,9 +522,15 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 
 }   // namespace v2
 
+// This file is compiled twice (Makefile): DN_V2_BF = 0 -> the fp32-MFMA kernels (dn_launch_rollout_v2), DN_V2_BF = 1 -> the
+// split-bf16 ones (dn_launch_rollout_v2_bf3); one translation unit each so that the two sets build in parallel.
+#ifndef DN_V2_BF
+#define DN_V2_BF 0
+#endif
+
 template <int MODEL, int NL, int ZD, int GM>
 static hipError_t launch_one(const V2Weights *d_w, const V2Run &r, hipStream_t st) {
-    hipLaunchKernelGGL((v2::rollout_v2_kernel<MODEL, NL, ZD, GM>), dim3(r.n_tiles), dim3(64), 0, st, d_w, r);
+    hipLaunchKernelGGL((v2::rollout_v2_kernel<MODEL, NL, ZD, GM, DN_V2_BF != 0>), dim3(r.n_tiles), dim3(64), 0, st, d_w, r);
     return hipGetLastError();
 }
 
@@ -536,8 +544,13 @@ static hipError_t launch_one(const V2Weights *d_w, const V2Run &r, hipStream_t s
     V2_CASE(2, 1, 32, 2) V2_CASE(2, 2, 16, 2)
 
 // returns hipErrorInvalidValue when the combination has no instantiation; d_w: DEVICE pointer to the model's V2Weights table
+#if DN_V2_BF
+extern "C" hipError_t dn_launch_rollout_v2_bf3(int model, int n_layers, int z_dim, int graph, const V2Weights *d_w, const V2Run *r,
+                                               hipStream_t st) {
+#else
 extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, int graph, const V2Weights *d_w, const V2Run *r,
                                            hipStream_t st) {
+#endif
     const int gm = graph == 2 ? 2 : 1;
 #define V2_CASE(M, L, Z, G) \
     if (model == M && n_layers == L && z_dim == Z && gm == G) return launch_one<M, L, Z, G>(d_w, *r, st);
@@ -546,6 +559,7 @@ extern "C" hipError_t dn_launch_rollout_v2(int model, int n_layers, int z_dim, i
     return hipErrorInvalidValue;
 }
 
+#if !DN_V2_BF
 extern "C" int dn_v2_has(int model, int n_layers, int z_dim, int graph) {
     const int gm = graph == 2 ? 2 : 1;
 #define V2_CASE(M, L, Z, G) \
@@ -554,3 +568,4 @@ extern "C" int dn_v2_has(int model, int n_layers, int z_dim, int graph) {
 #undef V2_CASE
     return 0;
 }
+#endif

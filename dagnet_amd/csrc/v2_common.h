@@ -82,27 +82,120 @@ __device__ __forceinline__ void zero(T16 (&x)[N]) {
         for (int r = 0; r < 16; ++r) x[t][r] = 0.f;
 }
 
-// One (n-tile, k-tile) block of packed weights: 4 x float4 per lane = the A (or B) operands of 16 MFMAs.
+// Weights in flight.  fp32 (BF = false): one (n-tile, k-tile) block = 4 x float4 per lane = the A (or B) operands of 16
+// v_mfma_f32_32x32x2_f32, in v[0..3].  Split bf16 (BF = true, params_v2.h): the unit is a HALF block - one output tile x one
+// k-half (16 input features) x three bf16 terms = 3 x 16 bytes per lane, the weight operands of 6 v_mfma_f32_32x32x16_bf16 -
+// and V2_BF_DEPTH of them are in flight: v[3*d + term] = half block d of the consumer's stream.
+#ifndef V2_BF_DEPTH
+#define V2_BF_DEPTH 2
+#endif
 struct WBlk {
-    float4 v[4];
+    float4 v[3 * V2_BF_DEPTH > 4 ? 3 * V2_BF_DEPTH : 4];
 };
-__device__ __forceinline__ WBlk wload(const WBuf &wp, int off, int lane) {
-    WBlk b;
+// the three quads of one half block into slot d
+__device__ __forceinline__ void wload_half(WBlk &b, int d, const WBuf &wp, int off, int lane) {
     asm volatile("" : "+s"(off));     // keep the scalar offset out of loop-invariant hoisting (SGPR spills)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) b.v[j] = wp.ld4(lane * 16 + j * 1024, off);
+    for (int j = 0; j < 3; ++j) b.v[3 * d + j] = wp.ld4(lane * 16 + j * 1024, off);
+}
+template <bool BF = false>
+__device__ __forceinline__ WBlk wload(const WBuf &wp, int off, int lane) {
+    WBlk b;
+    if constexpr (BF) {
+#pragma unroll
+        for (int d = 0; d < V2_BF_DEPTH; ++d) wload_half(b, d, wp, off + d * V2_HALF_BF3, lane);
+    } else {
+        asm volatile("" : "+s"(off));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b.v[j] = wp.ld4(lane * 16 + j * 1024, off);
+    }
     return b;
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ bf16x8 as_bf8(float4 v) { return __builtin_bit_cast(bf16x8, v); }
+
+// Registers 8p .. 8p+7 of an S- or T-layout tile as three bf16 terms, truncated (v_and / v_sub / v_perm: full-rate
+// instructions; 8 + 8 + 8 significant bits, so hi + mid + lo IS the value): t[term] = the 8 k-slots of one
+// v_mfma_f32_32x32x16_bf16 operand (slot s = register 8p + s: the order the weights are packed in, params_v2.h).
+struct XSplit {
+    float4 t[3];
+};
+__device__ __forceinline__ void split3(const T16 &x, int p, XSplit &s) {
+    unsigned pk[3][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v0 = x[8 * p + 2 * j], v1 = x[8 * p + 2 * j + 1];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const unsigned u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
+            pk[t][j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);      // {hi16(v1), hi16(v0)}
+            if (t < 2) {
+                v0 -= __uint_as_float(u0 & 0xffff0000u);
+                v1 -= __uint_as_float(u1 & 0xffff0000u);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        s.t[t] = make_float4(__uint_as_float(pk[t][0]), __uint_as_float(pk[t][1]), __uint_as_float(pk[t][2]), __uint_as_float(pk[t][3]));
 }
 
 // out[nt] += W(nt,kt) . x[kt]     TR = false: S <- S (weights are the A operand)
 //                                 TR = true : T <- S (weights are the B operand: out = x^T W^T)
-// Weight blocks are software pipelined two deep across the whole step: `pre` is this call's first
-// block (already in flight, issued by the previous call), `next_off` the first block of whatever
-// consumes weights next; the return value is that block, in flight.
-template <int NT, int KT, bool TR>
+// Weight blocks are software pipelined across the whole step: `pre` holds this call's first block(s) (already in flight,
+// issued by the previous call), `next_off` is the start of whatever consumes weights next; the return value is its first
+// block(s), in flight.
+// BF: the products run on the bf16 matrix pipe - x and W as three bf16 terms each, the six products whose terms' indices add
+// up to <= 2 (the dropped three are below 2^-24 of the largest), fp32 accumulation: 12 MFMAs of 32 clocks per 32 x 32 block
+// where the fp32 form takes 16 of 64.  The stream is ordered [kt][k-half p][nt]: half an input tile is split once (12
+// registers) and feeds all output tiles, then the other half.
+template <int NT, int KT, bool TR, bool BF = false>
 __device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, const T16 (&x)[KT], int lane, WBlk pre,
                                    int next_off) {
     constexpr int NB = NT * KT;
+    if constexpr (BF) {
+        constexpr int NH = 2 * NB, D = V2_BF_DEPTH;      // half blocks of this call (>= 2)
+        WBlk q = pre;
+        XSplit xs;
+#pragma unroll
+        for (int i = 0; i < NH; ++i) {
+            const int kt = i / (2 * NT), p = (i / NT) % 2, nt = i % NT, d = i % D;
+            if (nt == 0) split3(x[kt], p, xs);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 w0 = q.v[3 * d], w1 = q.v[3 * d + 1], w2 = q.v[3 * d + 2];
+            // smallest products first: W term tw with x terms 2 - tw .. 0
+            if (!TR) {
+                out[nt] = MFMA_BF(as_bf8(w2), as_bf8(xs.t[0]), out[nt]);
+                out[nt] = MFMA_BF(as_bf8(w1), as_bf8(xs.t[1]), out[nt]);
+                out[nt] = MFMA_BF(as_bf8(w1), as_bf8(xs.t[0]), out[nt]);
+                out[nt] = MFMA_BF(as_bf8(w0), as_bf8(xs.t[2]), out[nt]);
+                out[nt] = MFMA_BF(as_bf8(w0), as_bf8(xs.t[1]), out[nt]);
+                out[nt] = MFMA_BF(as_bf8(w0), as_bf8(xs.t[0]), out[nt]);
+            } else {
+                out[nt] = MFMA_BF(as_bf8(xs.t[0]), as_bf8(w2), out[nt]);
+                out[nt] = MFMA_BF(as_bf8(xs.t[1]), as_bf8(w1), out[nt]);
+                out[nt] = MFMA_BF(as_bf8(xs.t[0]), as_bf8(w1), out[nt]);
+                out[nt] = MFMA_BF(as_bf8(xs.t[2]), as_bf8(w0), out[nt]);
+                out[nt] = MFMA_BF(as_bf8(xs.t[1]), as_bf8(w0), out[nt]);
+                out[nt] = MFMA_BF(as_bf8(xs.t[0]), as_bf8(w0), out[nt]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // the slot just consumed takes half block i + D of this call, or the next consumer's
+            wload_half(q, d, wp, i + D < NH ? off + (i + D) * V2_HALF_BF3 : next_off + (i + D - NH) * V2_HALF_BF3, lane);
+        }
+        // slot d now holds the next consumer's half block (NH + d' ...) - rotate so that its half block 0 sits in slot 0
+        if constexpr (NH % D != 0) {
+            WBlk r;
+#pragma unroll
+            for (int d = 0; d < D; ++d)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) r.v[3 * d + j] = q.v[3 * ((d + NH) % D) + j];
+            return r;
+        }
+        return q;
+    } else {
 #if DN_V2_DEPTH == 2
     WBlk q0 = pre, q1, q2;
     q1 = wload(wp, NB > 1 ? off + 1024 : next_off, lane);
@@ -140,6 +233,7 @@ __device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, cons
 #endif
     }
     return q0;
+    }
 }
 
 // x[nt][r] += v[nt*32 + feature(r, h)]   for a vector stored [NT*32]
@@ -305,7 +399,7 @@ struct NoProf {
     __device__ __forceinline__ void operator()(int) const {}
 };
 // ph: stage timer of the diagnostic build (rollout_v2.hip PH(), tools/phase_profile.py); a no-op otherwise
-template <int KT, int NT, class PF = NoProf>
+template <int KT, int NT, bool BF = false, class PF = NoProf>
 __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WBuf &wp, const V2Gat &Gw, unsigned amask,
                                     float slope, float *xch, const float *gf, int lane, WBlk pre, int next_off, PF ph = PF()) {
     const int lh = lane >> 5, lc = lane & 31;
@@ -313,7 +407,8 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     T16 whT[1];
     zero(whT);
     const float a_src = gf[lc], a_dst = gf[32 + lc];
-    pre = mm<1, KT, true>(whT, wp, Gw.heads, x, lane, pre, Gw.out);
+    constexpr int BS = BF ? V2_BLOCK_BF3 : V2_BLOCK_F32;
+    pre = mm<1, KT, true, BF>(whT, wp, Gw.heads, x, lane, pre, Gw.out);
     ph(10);
     float u1[16], u2[16];
 #pragma unroll
@@ -391,7 +486,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     for (int nt = 0; nt < NT; ++nt) {      // one output tile at a time: Wh2^T tile -> aggregation (keeps 16, not NT*16, registers live)
         T16 wh2T[1];
         zero(wh2T);
-        pre = mm<1, 1, true>(wh2T, wp, Gw.out + nt * 1024, x2, lane, pre, nt + 1 < NT ? Gw.out + (nt + 1) * 1024 : next_off);
+        pre = mm<1, 1, true, BF>(wh2T, wp, Gw.out + nt * BS, x2, lane, pre, nt + 1 < NT ? Gw.out + (nt + 1) * BS : next_off);
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], alpha[r], out[nt]);
     }
@@ -415,13 +510,14 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
 // adjacency (adjv(r) = adj[row][tile row FR(r) + 4*lh], 0 outside the scene) the B operand of the aggregation.
 // V2Gat fields as used here: heads = W1 [1 tile (F <= 32)][KT], fold = [2][32] scale | shift of layer 1 (bias and eval
 // BatchNorm folded, zero beyond F), out = W2 [NT][1], bn = [2][NT*32] scale | shift of layer 2.
-template <int KT, int NT, class AdjFn>
+template <int KT, int NT, bool BF = false, class AdjFn = void>
 __device__ __forceinline__ WBlk gcn(const T16 (&x)[KT], T16 (&out)[NT], const WBuf &wp, const V2Gat &Gw, AdjFn adjv, int lane,
                                     WBlk pre, int next_off) {
     const int lh = lane >> 5;
+    constexpr int BS = BF ? V2_BLOCK_BF3 : V2_BLOCK_F32;
     T16 whT[1];
     zero(whT);
-    pre = mm<1, KT, true>(whT, wp, Gw.heads, x, lane, pre, Gw.out);
+    pre = mm<1, KT, true, BF>(whT, wp, Gw.heads, x, lane, pre, Gw.out);
     float av[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) av[r] = adjv(r);
@@ -440,7 +536,7 @@ __device__ __forceinline__ WBlk gcn(const T16 (&x)[KT], T16 (&out)[NT], const WB
     for (int nt = 0; nt < NT; ++nt) {
         T16 wh2T[1];
         zero(wh2T);
-        pre = mm<1, 1, true>(wh2T, wp, Gw.out + nt * 1024, x1, lane, pre, nt + 1 < NT ? Gw.out + (nt + 1) * 1024 : next_off);
+        pre = mm<1, 1, true, BF>(wh2T, wp, Gw.out + nt * BS, x1, lane, pre, nt + 1 < NT ? Gw.out + (nt + 1) * BS : next_off);
 #pragma unroll
         for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], av[r], out[nt]);
     }
@@ -470,7 +566,7 @@ __device__ __forceinline__ void gru_bias_to_lds(float *dst, const WBuf &wp, cons
 
 // One GRU layer.  xin: KX input tiles; h: 2 tiles (R = 64), updated in place.
 // LB: the layer's biases are in LDS at lb (gru_bias_to_lds); else they are loaded from the weight buffer.
-template <int KX, bool LB = false>
+template <int KX, bool LB = false, bool BF = false>
 __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBuf &wp, const V2Gru &Gw, int lane, WBlk pre,
                                     int next_off, const float *lb = nullptr) {
     const int lh = lane >> 5;
@@ -493,23 +589,24 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
         // gates one after the other so that only one accumulator plus two 16-register results are live:
         //   nh -> r -> t = r*(W_hn h + b_hn) -> n = tanh(W_in x + b_in + t) -> z -> h' = (1-z) n + z h
         // weights of a gate are packed per output tile: offset of tile nt = nt * KT * 1024 floats
-        const int ox = nt * KX * 1024, oh = nt * 2 * 1024;
+        constexpr int BS = BF ? V2_BLOCK_BF3 : V2_BLOCK_F32;
+        const int ox = nt * KX * BS, oh = nt * 2 * BS;
         T16 acc[1], tt, ng;
         init(acc[0], 0, Gw.nh.bias, nt);
-        pre = mm<1, 2, false>(acc, wp, Gw.nh.w[0] + oh, h, lane, pre, Gw.r.w[0] + ox);
+        pre = mm<1, 2, false, BF>(acc, wp, Gw.nh.w[0] + oh, h, lane, pre, Gw.r.w[0] + ox);
         tt = acc[0];
         init(acc[0], 1, Gw.r.bias, nt);
-        pre = mm<1, KX, false>(acc, wp, Gw.r.w[0] + ox, xin, lane, pre, Gw.r.w[1] + oh);
-        pre = mm<1, 2, false>(acc, wp, Gw.r.w[1] + oh, h, lane, pre, Gw.ni.w[0] + ox);
+        pre = mm<1, KX, false, BF>(acc, wp, Gw.r.w[0] + ox, xin, lane, pre, Gw.r.w[1] + oh);
+        pre = mm<1, 2, false, BF>(acc, wp, Gw.r.w[1] + oh, h, lane, pre, Gw.ni.w[0] + ox);
 #pragma unroll
         for (int r = 0; r < 16; ++r) tt[r] *= sigm2(acc[0][r]);
         init(acc[0], 2, Gw.ni.bias, nt);
-        pre = mm<1, KX, false>(acc, wp, Gw.ni.w[0] + ox, xin, lane, pre, Gw.z.w[0] + ox);
+        pre = mm<1, KX, false, BF>(acc, wp, Gw.ni.w[0] + ox, xin, lane, pre, Gw.z.w[0] + ox);
 #pragma unroll
         for (int r = 0; r < 16; ++r) ng[r] = tanh2(acc[0][r] + tt[r]);
         init(acc[0], 3, Gw.z.bias, nt);
-        pre = mm<1, KX, false>(acc, wp, Gw.z.w[0] + ox, xin, lane, pre, Gw.z.w[1] + oh);
-        pre = mm<1, 2, false>(acc, wp, Gw.z.w[1] + oh, h, lane, pre, nt == 0 ? Gw.nh.w[0] + 2 * 1024 : next_off);
+        pre = mm<1, KX, false, BF>(acc, wp, Gw.z.w[0] + ox, xin, lane, pre, Gw.z.w[1] + oh);
+        pre = mm<1, 2, false, BF>(acc, wp, Gw.z.w[1] + oh, h, lane, pre, nt == 0 ? Gw.nh.w[0] + 2 * BS : next_off);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float zg = sigm2(acc[0][r]);

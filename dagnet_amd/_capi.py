@@ -13,7 +13,8 @@ from typing import Dict, Optional, Sequence
 import numpy as np
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libdagnet_hip.so")
+# DAGNET_HIP_LIB: another build of the same library (kernel experiments: tools/variants.sh); the package never falls back to it
+_LIB_PATH = os.environ.get("DAGNET_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_lib", "libdagnet_hip.so")
 _lib = None
 _lock = threading.Lock()
 

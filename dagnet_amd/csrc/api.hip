@@ -462,79 +462,94 @@ DnGru pack_gru(Packer &pk, int l, int R, int H) {
 }
 
 // ---- register-resident kernel (rollout_v2.hip): same tensors, MFMA-chain packing -------------
+// Every function packs in two parts, in the order of params_v2.h v2_layout(): part 0 = one weight segment (they are laid out
+// in the order a rollout step consumes them), part 1 = the layer's vectors (bias, one-hot table, attention vectors).
 // Npad / Gpad / SegSpec.kpad: sizes the segment is padded to (zeros), so that the layout of an instantiation does not
 // depend on g_dim or n_max_agents (params_v2.h v2_layout)
 // logits: the layer feeds a softmax over its N outputs and nothing else - weights and bias are scaled by log2(e) (the
 // kernels' softmax is exp2(x - max)) and the bias of the padded outputs is -inf, so they come out as exactly 0 without a mask.
-V2Lin v2_linear(Packer &pk, const std::string &name, int N, int Ktot, std::vector<SegSpec> segs, int gcol0 = -1, int G = 0,
-                int Npad = 0, int Gpad = 0, bool logits = false) {
-    V2Lin L;
+struct V2LinSpec {
+    std::string name;
+    int N, Ktot;
+    std::vector<SegSpec> segs;
+    int gcol0 = -1, G = 0, Npad = 0, Gpad = 0;
+    bool logits = false;
+};
+void v2_lin_init(V2Lin &L) {
     L.w[0] = L.w[1] = L.w[2] = 0;
     L.bias = L.gather = -1;
-    const Tensor *W = pk.get(name + ".weight", {N, Ktot});
-    const Tensor *B = pk.get(name + ".bias", {N});
-    if (!W || !B) return L;
+}
+// weight segment s of the layer
+void v2_lin_w(Packer &pk, V2Lin &L, const V2LinSpec &sp, int s) {
+    const Tensor *W = pk.get(sp.name + ".weight", {sp.N, sp.Ktot});
+    if (!W) return;
+    const float *w = W->p;
+    const int N = sp.N, Ktot = sp.Ktot, Np = std::max(sp.N, sp.Npad);
+    const float sc = sp.logits ? 1.44269504088896340736f : 1.0f;
+    const int c0 = sp.segs[s].col0, Ks = sp.segs[s].K;
+    L.w[s] = pk.chain_v2([=](int n, int k) { return (n < N && k < Ks) ? sc * w[(size_t)n * Ktot + c0 + k] : 0.f; }, Np, std::max(Ks, sp.segs[s].kpad), true);
+}
+void v2_lin_v(Packer &pk, V2Lin &L, const V2LinSpec &sp) {
+    const Tensor *W = pk.get(sp.name + ".weight", {sp.N, sp.Ktot});
+    const Tensor *B = pk.get(sp.name + ".bias", {sp.N});
+    if (!W || !B) return;
     const float *w = W->p, *b = B->p;
-    const int Np = std::max(N, Npad);
-    const float sc = logits ? 1.44269504088896340736f : 1.0f;
-    for (size_t s = 0; s < segs.size(); ++s) {
-        const int c0 = segs[s].col0;
-        const int Ks = segs[s].K;
-        L.w[s] = pk.chain_v2([=](int n, int k) { return (n < N && k < Ks) ? sc * w[(size_t)n * Ktot + c0 + k] : 0.f; }, Np, std::max(Ks, segs[s].kpad), true);
-    }
-    if (logits) L.bias = pk.vec([=](int n) { return n < N ? sc * b[n] : -INFINITY; }, pad32(Np), pad32(Np));
+    const int N = sp.N, Ktot = sp.Ktot, Np = std::max(sp.N, sp.Npad), gcol0 = sp.gcol0;
+    const float sc = sp.logits ? 1.44269504088896340736f : 1.0f;
+    if (sp.logits) L.bias = pk.vec([=](int n) { return n < N ? sc * b[n] : -INFINITY; }, pad32(Np), pad32(Np));
     else L.bias = pk.vec([=](int n) { return b[n]; }, N, pad32(Np));
-    // one-hot input: row g of the table = column gcol0 + g of the weight PLUS the bias (v2_common.h finish<> loads one row)
-    if (gcol0 >= 0) L.gather = pk.gather([=](int n, int g) { return w[(size_t)n * Ktot + gcol0 + g] + b[n]; }, N, G, Gpad);
-    return L;
+    // one-hot input: row g of the table = column gcol0 + g of the weight PLUS the bias (v2_common.h start<> loads one row)
+    if (gcol0 >= 0) L.gather = pk.gather([=](int n, int g) { return w[(size_t)n * Ktot + gcol0 + g] + b[n]; }, N, sp.G, sp.Gpad);
 }
 
-V2Lin v2_pair(Packer &pk, const std::string &a, const std::string &b, int Z, int K) {
-    V2Lin L;
-    L.w[0] = L.w[1] = L.w[2] = 0;
-    L.bias = L.gather = -1;
+// two heads stacked: rows [0,Z) from a, [Z,2Z) from b   (mean / logvar)
+void v2_pair(Packer &pk, V2Lin &L, const std::string &a, const std::string &b, int Z, int K, int part) {
     const Tensor *Wa = pk.get(a + ".weight", {Z, K}), *Wb = pk.get(b + ".weight", {Z, K});
     const Tensor *Ba = pk.get(a + ".bias", {Z}), *Bb = pk.get(b + ".bias", {Z});
-    if (!Wa || !Wb || !Ba || !Bb) return L;
+    if (!Wa || !Wb || !Ba || !Bb) return;
     const float *wa = Wa->p, *wb = Wb->p, *ba = Ba->p, *bb = Bb->p;
-    L.w[0] = pk.chain_v2([=](int n, int k) { return n < Z ? wa[(size_t)n * K + k] : wb[(size_t)(n - Z) * K + k]; }, 2 * Z, K, true);
-    L.bias = pk.vec([=](int n) { return n < Z ? ba[n] : bb[n - Z]; }, 2 * Z, pad32(2 * Z));
-    return L;
+    if (part == 0) L.w[0] = pk.chain_v2([=](int n, int k) { return n < Z ? wa[(size_t)n * K + k] : wb[(size_t)(n - Z) * K + k]; }, 2 * Z, K, true);
+    else L.bias = pk.vec([=](int n) { return n < Z ? ba[n] : bb[n - Z]; }, 2 * Z, pad32(2 * Z));
 }
 
 // pad: nin and nout are padded to this many features (the goal graph: V2_GT tiles whatever g_dim is)
 static const double kLog2e = 1.4426950408889634074;
 static const double kTanhScale = 2.0 * kLog2e, kSigmScale = -kLog2e;   // v2_common.h tanh2() / sigm2()
-V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, int P, int pad = 0) {
-    V2Gat g;
-    memset(&g, 0, sizeof(g));
+// part 0: heads, 1: out (both weight segments), 2: vectors
+void v2_gat(Packer &pk, V2Gat &g, const std::string &prefix, int nin, int nout, int F, int P, int pad, int part) {
     g.nout = nout;
     std::vector<const float *> Wh(P), ah(P);
     for (int p = 0; p < P; ++p) {
         const Tensor *W = pk.get(prefix + ".attention_" + std::to_string(p) + ".W", {nin, F});
         const Tensor *a = pk.get(prefix + ".attention_" + std::to_string(p) + ".a", {2 * F, 1});
-        if (!W || !a) return g;
+        if (!W || !a) return;
         Wh[p] = W->p;
         ah[p] = a->p;
     }
     const Tensor *Wo = pk.get(prefix + ".out_att.W", {P * F, nout});
     const Tensor *ao = pk.get(prefix + ".out_att.a", {2 * nout, 1});
-    if (!Wo || !ao) return g;
+    if (!Wo || !ao) return;
     const float *wo = Wo->p, *aop = ao->p;
     const int ninp = std::max(nin, pad), noutp = std::max(nout, pad);
-    g.heads = pk.chain_v2([=](int n, int k) { return k < nin ? Wh[n / F][(size_t)k * F + (n % F)] : 0.f; }, P * F, ninp, false);
+    const Tensor *ga = pk.get(prefix + ".bn1.weight", {nout}), *be = pk.get(prefix + ".bn1.bias", {nout});
+    const Tensor *mu = pk.get(prefix + ".bn1.running_mean", {nout}), *var = pk.get(prefix + ".bn1.running_var", {nout});
+    if (!ga || !be || !mu || !var) return;
+    const float *gp = ga->p, *bp = be->p, *mp = mu->p, *vp = var->p;
+    if (part == 0) {
+        g.heads = pk.chain_v2([=](int n, int k) { return k < nin ? Wh[n / F][(size_t)k * F + (n % F)] : 0.f; }, P * F, ninp, false);
+        return;
+    }
+    if (part == 1) {
+        // eval-mode BatchNorm y = x * scale + shift and the factor 2 log2(e) of the kernels' tanh2() (v2_common.h): the scale
+        // goes into the out_att weights (the attention sums over rows, the scale is per feature), the shift into g.bn
+        g.out = pk.chain_v2(
+            [=](int n, int k) { return n < nout ? (float)(kTanhScale * (gp[n] / sqrtf(vp[n] + 1e-5f)) * wo[(size_t)k * nout + n]) : 0.f; },
+            noutp, P * F, false);
+        return;
+    }
     // attention vectors of the heads for the per-lane logit reduction (v2_common.h gat<>): entry 8p+f = a_p[f] (source half)
     // and 32 + 8p+f = a_p[F+f] (destination half), in the log2 domain: the kernels' softmax is exp2(e - max)
     g.fold = pk.vec([=](int i) { const int q = i & 31; return (float)((double)ah[q / F][(i >> 5) * F + (q % F)] * kLog2e); }, 64, 64);
-    const Tensor *ga = pk.get(prefix + ".bn1.weight", {nout}), *be = pk.get(prefix + ".bn1.bias", {nout});
-    const Tensor *mu = pk.get(prefix + ".bn1.running_mean", {nout}), *var = pk.get(prefix + ".bn1.running_var", {nout});
-    if (!ga || !be || !mu || !var) return g;
-    const float *gp = ga->p, *bp = be->p, *mp = mu->p, *vp = var->p;
-    // eval-mode BatchNorm y = x * scale + shift and the factor 2 log2(e) of the kernels' tanh2() (v2_common.h): the scale
-    // goes into the out_att weights (the attention sums over rows, the scale is per feature), the shift into g.bn
-    g.out = pk.chain_v2(
-        [=](int n, int k) { return n < nout ? (float)(kTanhScale * (gp[n] / sqrtf(vp[n] + 1e-5f)) * wo[(size_t)k * nout + n]) : 0.f; },
-        noutp, P * F, false);
     // a_out . (x2 W_out) == x2 . (W_out a_out): the out head's two logit dot products over its 32 input features
     g.fold_out = pk.vec(
         [=](int i) {
@@ -552,24 +567,27 @@ V2Gat v2_gat(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
             return (float)(kTanhScale * (bp[c] - mp[c] * sc));
         },
         ld, 2 * ld);        // second row unused (params_v2.h keeps one table size for GAT and GCN)
-    return g;
 }
 
 // GCN in the V2Gat slots (v2_common.h gcn<>): heads = W1, fold = layer-1 scale|shift, out = W2, bn = layer-2 scale|shift;
 // bias and eval BatchNorm folded: y = agg * sc + ((b - mean) * sc + beta), sc = gamma / sqrt(var + eps)
-V2Gat v2_gcn(Packer &pk, const std::string &prefix, int nin, int nout, int F, int pad = 0) {
-    V2Gat g;
-    memset(&g, 0, sizeof(g));
+void v2_gcn(Packer &pk, V2Gat &g, const std::string &prefix, int nin, int nout, int F, int pad, int part) {
     g.nout = nout;
     const Tensor *W1 = pk.get(prefix + ".gc1.weight", {nin, F}), *W2 = pk.get(prefix + ".gc2.weight", {F, nout});
-    if (!W1 || !W2) return g;
+    if (!W1 || !W2) return;
     const float *w1 = W1->p, *w2 = W2->p;
     const float *b1 = nullptr, *b2 = nullptr;
     if (pk.has(prefix + ".gc1.bias")) { const Tensor *b = pk.get(prefix + ".gc1.bias", {F}); if (b) b1 = b->p; }
     if (pk.has(prefix + ".gc2.bias")) { const Tensor *b = pk.get(prefix + ".gc2.bias", {nout}); if (b) b2 = b->p; }
     const int ninp = std::max(nin, pad), noutp = std::max(nout, pad);
-    g.heads = pk.chain_v2([=](int n, int k) { return k < nin ? w1[(size_t)k * F + n] : 0.f; }, F, ninp, false);
-    g.out = pk.chain_v2([=](int n, int k) { return n < nout ? w2[(size_t)k * nout + n] : 0.f; }, noutp, F, false);
+    if (part == 0) {
+        g.heads = pk.chain_v2([=](int n, int k) { return k < nin ? w1[(size_t)k * F + n] : 0.f; }, F, ninp, false);
+        return;
+    }
+    if (part == 1) {
+        g.out = pk.chain_v2([=](int n, int k) { return n < nout ? w2[(size_t)k * nout + n] : 0.f; }, noutp, F, false);
+        return;
+    }
     auto fold = [&](const std::string &bn, int n, const float *bias, int ld, double act) {
         const Tensor *ga = pk.get(bn + ".weight", {n}), *be = pk.get(bn + ".bias", {n});
         const Tensor *mu = pk.get(bn + ".running_mean", {n}), *var = pk.get(bn + ".running_var", {n});
@@ -586,36 +604,47 @@ V2Gat v2_gcn(Packer &pk, const std::string &prefix, int nin, int nout, int F, in
     };
     g.fold = fold(prefix + ".bn1", F, b1, 32, 1.0);
     g.bn = fold(prefix + ".bn2", nout, b2, pad32(noutp), kTanhScale);       // layer 2 ends in tanh2()
-    return g;
 }
 
-V2Gru v2_gru(Packer &pk, int l, int R, int H) {
-    V2Gru g;
-    memset(&g, 0, sizeof(g));
+// part 0: the six weight segments in the order the kernels' GRU consumes them (nh, r.x, r.h, ni, z.x, z.h); part 1: biases.
+// fp32 blocks are [nt][kt] (one output tile per product); split-bf16 ones [kt][p][nt] (both output tiles per product:
+// v2_common.h gru<>, BF).
+void v2_gru(Packer &pk, V2Gru &g, int l, int R, int H, int part) {
     const int Kin = l == 0 ? 2 * H : R;
     const std::string sl = std::to_string(l);
     const Tensor *Wi = pk.get("rnn.weight_ih_l" + sl, {3 * R, Kin});
     const Tensor *Wh = pk.get("rnn.weight_hh_l" + sl, {3 * R, R});
     const Tensor *Bi = pk.get("rnn.bias_ih_l" + sl, {3 * R});
     const Tensor *Bh = pk.get("rnn.bias_hh_l" + sl, {3 * R});
-    if (!Wi || !Wh || !Bi || !Bh) return g;
+    if (!Wi || !Wh || !Bi || !Bh) return;
     const float *wi = Wi->p, *wh = Wh->p, *bi = Bi->p, *bh = Bh->p;
     // gate pre-activations come out already scaled for sigm2() / tanh2() (v2_common.h): r, z by -log2(e); both halves of
     // the candidate (W_in x + b_in and W_hn h + b_hn, the latter multiplied by r in between) by 2 log2(e)
+    if (pk.bf && part == 0) {
+        // split-bf16 kernels (v2_common.h gru<>, BF): two dense layers with 3 R outputs each - W_ih with its gates in the order
+        // n, r, z and W_hh in the order r, z, n - so that an input tile is split once for all gates
+        const int gx[3] = {2, 0, 1}, gh[3] = {0, 1, 2};
+        auto scale = [](int gate) { return gate == 2 ? kTanhScale : kSigmScale; };
+        g.r.w[0] = pk.chain_v2([=](int n, int k) { const int gate = gx[n / R]; return (float)(scale(gate) * wi[(size_t)(gate * R + n % R) * Kin + k]); },
+                               3 * R, Kin, true);
+        g.r.w[1] = pk.chain_v2([=](int n, int k) { const int gate = gh[n / R]; return (float)(scale(gate) * wh[(size_t)(gate * R + n % R) * R + k]); },
+                               3 * R, R, true);
+        return;
+    }
     auto mk = [&](V2Lin &L, int gate, bool with_x, bool with_h) {
-        L.w[0] = L.w[1] = L.w[2] = 0;
-        L.gather = -1;
         int s = 0;
         const double a = gate == 2 ? kTanhScale : kSigmScale;
-        if (with_x) L.w[s++] = pk.chain_v2([=](int n, int k) { return (float)(a * wi[(size_t)(gate * R + n) * Kin + k]); }, R, Kin, false);
-        if (with_h) L.w[s++] = pk.chain_v2([=](int n, int k) { return (float)(a * wh[(size_t)(gate * R + n) * R + k]); }, R, R, false);
-        L.bias = pk.vec([=](int n) { return (float)(a * ((with_x ? bi[gate * R + n] : 0.f) + (with_h ? bh[gate * R + n] : 0.f))); }, R, pad32(R));
+        if (part == 0) {
+            if (with_x) L.w[s++] = pk.chain_v2([=](int n, int k) { return (float)(a * wi[(size_t)(gate * R + n) * Kin + k]); }, R, Kin, true);
+            if (with_h) L.w[s++] = pk.chain_v2([=](int n, int k) { return (float)(a * wh[(size_t)(gate * R + n) * R + k]); }, R, R, true);
+        } else {
+            L.bias = pk.vec([=](int n) { return (float)(a * ((with_x ? bi[gate * R + n] : 0.f) + (with_h ? bh[gate * R + n] : 0.f))); }, R, pad32(R));
+        }
     };
-    mk(g.r, 0, true, true);
-    mk(g.z, 1, true, true);
-    mk(g.ni, 2, true, false);
     mk(g.nh, 2, false, true);
-    return g;
+    mk(g.r, 0, true, true);
+    mk(g.ni, 2, true, false);
+    mk(g.z, 1, true, true);
 }
 
 bool v2_eligible(const dagnet_config &c) {
@@ -709,46 +738,88 @@ void v2_pack(Packer &pk, const dagnet_config &c, V2Weights &W, bool ext = false)
     memset(&W, 0, sizeof(W));
     const int H = 64, R = 64, Z = c.z_dim, G = c.g_dim, Dd = 2 * c.n_max_agents;
     const bool dag = c.model == DAGNET_MODEL_DAGNET, graph = c.model != DAGNET_MODEL_VRNN;
+    const bool head = dag && !ext, gcn = c.graph_model == DAGNET_GRAPH_GCN;
     const int GP = V2_GT * 32;                       // goal-wide dims are padded to V2_GT tiles
-    const int DP = (ext || Dd > 32) ? 64 : 32;       // disposition tiles
-    DnRaw px0 = pack_raw_linear(pk, "phi_x.0", H, 2), dm = pack_raw_linear(pk, "dec_mean", 2, H);
+    const int DP = (ext || Dd > 32) ? 64 : 32;       // disposition tiles (model 3 multiplies two whatever n_max_agents is)
+    const std::string hid = dag ? "graph_hiddens" : "graph";
+    V2LinSpec dec_goal0{"dec_goal.0", H, Dd + R + G, {{0, Dd, DP}, {Dd, R}}, Dd + R, G, 0, GP};
+    V2LinSpec dec_goal2{"dec_goal.2", G, H, {{0, H}}, -1, 0, GP, 0, true};
+    V2LinSpec lg_goals{"lg_goals.0", G, 2 * G, {{0, G, GP}, {G, G, GP}}, -1, 0, GP, 0, true};
+    V2LinSpec prior0 = dag ? V2LinSpec{"prior.0", H, G + R, {{G, R}}, 0, G, 0, GP} : V2LinSpec{"prior.0", H, R, {{0, R}}};
+    V2LinSpec prior2{"prior.2", H, H, {{0, H}}};
+    V2LinSpec phi_z0{"phi_z.0", H, Z, {{0, Z}}}, phi_z2{"phi_z.2", H, H, {{0, H}}};
+    V2LinSpec dec0 = dag ? V2LinSpec{"dec.0", H, Dd + G + H + R, {{0, Dd, DP}, {Dd + G, H}, {Dd + G + H, R}}, Dd, G, 0, GP}
+                         : V2LinSpec{"dec.0", H, H + R, {{0, H}, {H, R}}};
+    V2LinSpec dec2{"dec.2", H, H, {{0, H}}}, phi_x2{"phi_x.2", H, H, {{0, H}}};
+    V2LinSpec blend{dag ? "lg_hiddens" : "lg", R, 2 * R, {{0, R}, {R, R}}};
+    V2LinSpec enc0 = dag ? V2LinSpec{"enc.0", H, H + G + R, {{0, H}, {H + G, R}}, H, G, 0, GP} : V2LinSpec{"enc.0", H, H + R, {{0, H}, {H, R}}};
+    V2LinSpec enc2{"enc.2", H, H, {{0, H}}};
+    for (V2Lin *L : {&W.phi_x2, &W.phi_z0, &W.phi_z2, &W.prior0, &W.prior2, &W.prior_ml, &W.dec0, &W.dec2, &W.blend, &W.dec_goal0, &W.dec_goal2,
+                     &W.lg_goals, &W.enc0, &W.enc2, &W.enc_ml})
+        v2_lin_init(*L);
+    for (int l = 0; l < 2; ++l)
+        for (V2Lin *L : {&W.gru[l].r, &W.gru[l].z, &W.gru[l].ni, &W.gru[l].nh}) v2_lin_init(*L);
+    auto graphnet = [&](V2Gat &g, const std::string &prefix, int nin, int nout, int pad, int part) {
+        if (gcn) v2_gcn(pk, g, prefix, nin, nout, c.graph_hid, pad, part);
+        else v2_gat(pk, g, prefix, nin, nout, c.graph_hid, c.n_heads, pad, part);
+    };
+    // ---- the weight stream of one rollout step, in the order it is consumed (params_v2.h v2_layout)
+    if (head) {
+        v2_lin_w(pk, W.dec_goal0, dec_goal0, 0);
+        v2_lin_w(pk, W.dec_goal0, dec_goal0, 1);
+        v2_lin_w(pk, W.dec_goal2, dec_goal2, 0);
+        v2_lin_w(pk, W.lg_goals, lg_goals, 0);
+        graphnet(W.g_goal, "graph_goals", G, G, GP, 0);
+        graphnet(W.g_goal, "graph_goals", G, G, GP, 1);
+        v2_lin_w(pk, W.lg_goals, lg_goals, 1);
+    }
+    v2_lin_w(pk, W.prior0, prior0, 0);
+    v2_lin_w(pk, W.prior2, prior2, 0);
+    v2_pair(pk, W.prior_ml, "prior_mean", "prior_logvar", Z, H, 0);
+    v2_lin_w(pk, W.phi_z0, phi_z0, 0);
+    v2_lin_w(pk, W.phi_z2, phi_z2, 0);
+    for (size_t s = 0; s < dec0.segs.size(); ++s) v2_lin_w(pk, W.dec0, dec0, (int)s);
+    v2_lin_w(pk, W.dec2, dec2, 0);
+    v2_lin_w(pk, W.phi_x2, phi_x2, 0);
+    for (int l = 0; l < c.n_layers; ++l) v2_gru(pk, W.gru[l], l, R, H, 0);
+    if (graph) {
+        graphnet(W.g_hid, hid, R, R, 0, 0);
+        graphnet(W.g_hid, hid, R, R, 0, 1);
+        v2_lin_w(pk, W.blend, blend, 0);
+        v2_lin_w(pk, W.blend, blend, 1);
+    }
+    // ---- teacher-forced pass only (forward_v2.hip)
+    v2_lin_w(pk, W.enc0, enc0, 0);
+    v2_lin_w(pk, W.enc0, enc0, 1);
+    v2_lin_w(pk, W.enc2, enc2, 0);
+    v2_pair(pk, W.enc_ml, "enc_mean", "enc_logvar", Z, H, 0);
+    // ---- vectors
+    if (head) {
+        v2_lin_v(pk, W.dec_goal0, dec_goal0);
+        v2_lin_v(pk, W.dec_goal2, dec_goal2);
+        v2_lin_v(pk, W.lg_goals, lg_goals);
+        graphnet(W.g_goal, "graph_goals", G, G, GP, 2);
+    }
+    v2_lin_v(pk, W.prior0, prior0);
+    v2_lin_v(pk, W.prior2, prior2);
+    v2_pair(pk, W.prior_ml, "prior_mean", "prior_logvar", Z, H, 1);
+    v2_lin_v(pk, W.phi_z0, phi_z0);
+    v2_lin_v(pk, W.phi_z2, phi_z2);
+    v2_lin_v(pk, W.dec0, dec0);
+    v2_lin_v(pk, W.dec2, dec2);
+    v2_lin_v(pk, W.phi_x2, phi_x2);
+    for (int l = 0; l < c.n_layers; ++l) v2_gru(pk, W.gru[l], l, R, H, 1);
+    if (graph) {
+        graphnet(W.g_hid, hid, R, R, 0, 2);
+        v2_lin_v(pk, W.blend, blend);
+    }
+    v2_lin_v(pk, W.enc0, enc0);
+    v2_lin_v(pk, W.enc2, enc2);
+    v2_pair(pk, W.enc_ml, "enc_mean", "enc_logvar", Z, H, 1);
+    DnRaw px0 = pack_raw_linear(pk, "phi_x.0", H, 2), dm = pack_raw_linear(pk, "dec_mean", 2, H), dl = pack_raw_linear(pk, "dec_logvar", 2, H);
     W.phi_x0_w = px0.w; W.phi_x0_b = px0.b;
     W.dec_mean_w = dm.w; W.dec_mean_b = dm.b;
-    W.phi_x2 = v2_linear(pk, "phi_x.2", H, H, {{0, H}});
-    W.phi_z0 = v2_linear(pk, "phi_z.0", H, Z, {{0, Z}});
-    W.phi_z2 = v2_linear(pk, "phi_z.2", H, H, {{0, H}});
-    if (dag) {
-        W.prior0 = v2_linear(pk, "prior.0", H, G + R, {{G, R}}, 0, G, 0, GP);
-        // model 3 multiplies two disposition tiles whatever n_max_agents is
-        W.dec0 = v2_linear(pk, "dec.0", H, Dd + G + H + R, {{0, Dd, DP}, {Dd + G, H}, {Dd + G + H, R}}, Dd, G, 0, GP);
-    } else {
-        W.prior0 = v2_linear(pk, "prior.0", H, R, {{0, R}});
-        W.dec0 = v2_linear(pk, "dec.0", H, H + R, {{0, H}, {H, R}});
-    }
-    W.prior2 = v2_linear(pk, "prior.2", H, H, {{0, H}});
-    W.prior_ml = v2_pair(pk, "prior_mean", "prior_logvar", Z, H);
-    {               // teacher-forced pass (forward_v2.hip)
-        if (dag) W.enc0 = v2_linear(pk, "enc.0", H, H + G + R, {{0, H}, {H + G, R}}, H, G, 0, GP);
-        else W.enc0 = v2_linear(pk, "enc.0", H, H + R, {{0, H}, {H, R}});
-        W.enc2 = v2_linear(pk, "enc.2", H, H, {{0, H}});
-        W.enc_ml = v2_pair(pk, "enc_mean", "enc_logvar", Z, H);
-        DnRaw dl = pack_raw_linear(pk, "dec_logvar", 2, H);
-        W.dec_logvar_w = dl.w; W.dec_logvar_b = dl.b;
-    }
-    W.dec2 = v2_linear(pk, "dec.2", H, H, {{0, H}});
-    for (int l = 0; l < c.n_layers; ++l) W.gru[l] = v2_gru(pk, l, R, H);
-    if (graph) {
-        W.g_hid = c.graph_model == DAGNET_GRAPH_GCN ? v2_gcn(pk, dag ? "graph_hiddens" : "graph", R, R, c.graph_hid)
-                                                    : v2_gat(pk, dag ? "graph_hiddens" : "graph", R, R, c.graph_hid, c.n_heads);
-        W.blend = v2_linear(pk, dag ? "lg_hiddens" : "lg", R, 2 * R, {{0, R}, {R, R}});
-    }
-    if (dag && !ext) {
-        W.dec_goal0 = v2_linear(pk, "dec_goal.0", H, Dd + R + G, {{0, Dd, DP}, {Dd, R}}, Dd + R, G, 0, GP);
-        W.dec_goal2 = v2_linear(pk, "dec_goal.2", G, H, {{0, H}}, -1, 0, GP, 0, true);
-        W.g_goal = c.graph_model == DAGNET_GRAPH_GCN ? v2_gcn(pk, "graph_goals", G, G, c.graph_hid, GP)
-                                                     : v2_gat(pk, "graph_goals", G, G, c.graph_hid, c.n_heads, GP);
-        W.lg_goals = v2_linear(pk, "lg_goals.0", G, 2 * G, {{0, G, GP}, {G, G, GP}}, -1, 0, GP, 0, true);
-    }
+    W.dec_logvar_w = dl.w; W.dec_logvar_b = dl.b;
 }
 
 

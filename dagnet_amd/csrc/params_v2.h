@@ -74,6 +74,11 @@ struct V2Layout {
     int32_t total;      // floats in the v2 region
 };
 
+// Order of the region: first every MFMA-packed weight segment in the order in which one time step of the rollout kernel
+// consumes them (goal head, prior, phi_z, decoder, phi_x, GRU gates nh / r / ni / z per layer, hidden graph, blend) - so the
+// kernel's weight stream is ONE ascending sequence of blocks per step and a prefetch of any depth simply runs ahead into the
+// next segment (v2_common.h mm<>) - then the segments only the teacher-forced pass reads, then all vectors (biases, one-hot
+// tables, attention vectors, the raw phi_x.0 / dec_mean / dec_logvar layers).
 constexpr V2Layout v2_layout(int model, int nl, int zd, int gm, int bf = 0) {
     V2Layout L{};
     int32_t cur = 0;
@@ -81,76 +86,108 @@ constexpr V2Layout v2_layout(int model, int nl, int zd, int gm, int bf = 0) {
     const bool dag = model >= 2, graph = model != 0, head = model == 2 || model == 4;
     const int DT = (model == 3 || model == 4) ? 2 : 1, GT = V2_GT, GP = V2_GT * 32;
     const int zt2 = (2 * zd + 31) / 32;
-    auto take = [&cur](int32_t &o, int32_t &u, int n) {
+    V2Weights &o = L.off, &u = L.used;
+    auto take = [&cur](int32_t &off, int32_t &used, int n) {
         cur = (cur + 3) & ~3;
-        o = cur;
-        u = 1;
+        off = cur;
+        used = 1;
         cur += n;
     };
-    // dense layer: chain segments [nt][k_i] (k_i = 0: absent), bias [nt*32], optional one-hot table [GP][nt*32]
-    auto lin = [&](V2Lin &o, V2Lin &u, int nt, int k0, int k1, int k2, bool gather) {
-        o.bias = -1;
-        o.gather = -1;
-        if (k0) take(o.w[0], u.w[0], nt * k0 * BS);
-        if (k1) take(o.w[1], u.w[1], nt * k1 * BS);
-        if (k2) take(o.w[2], u.w[2], nt * k2 * BS);
-        take(o.bias, u.bias, nt * 32);
-        if (gather) take(o.gather, u.gather, GP * nt * 32);
-    };
-    auto raw = [&](int32_t &w, int32_t &uw, int32_t &b, int32_t &ub, int nw, int nb) {
-        take(w, uw, nw);
-        take(b, ub, nb);
-    };
-    auto graphnet = [&](V2Gat &o, V2Gat &u, int kt, int nt) {
-        if (gm == 2) {      // GCN: heads = W1, out = W2, fold / bn = folded scale | shift of the two layers
-            take(o.heads, u.heads, kt * BS);
-            take(o.out, u.out, nt * BS);
-            take(o.fold, u.fold, 64);
-            take(o.bn, u.bn, 2 * nt * 32);
-        } else {
-            take(o.heads, u.heads, kt * BS);
-            take(o.fold, u.fold, 64);
-            take(o.out, u.out, nt * BS);
-            take(o.fold_out, u.fold_out, 64);
-            take(o.bn, u.bn, 2 * nt * 32);
-        }
-    };
-    raw(L.off.phi_x0_w, L.used.phi_x0_w, L.off.phi_x0_b, L.used.phi_x0_b, 128, 64);
-    raw(L.off.dec_mean_w, L.used.dec_mean_w, L.off.dec_mean_b, L.used.dec_mean_b, 128, 2);
-    lin(L.off.phi_x2, L.used.phi_x2, 2, 2, 0, 0, false);
-    lin(L.off.phi_z0, L.used.phi_z0, 2, (zd + 31) / 32, 0, 0, false);
-    lin(L.off.phi_z2, L.used.phi_z2, 2, 2, 0, 0, false);
-    if (dag) {
-        lin(L.off.prior0, L.used.prior0, 2, 2, 0, 0, true);
-        lin(L.off.dec0, L.used.dec0, 2, DT, 2, 2, true);
-    } else {
-        lin(L.off.prior0, L.used.prior0, 2, 2, 0, 0, false);
-        lin(L.off.dec0, L.used.dec0, 2, 2, 2, 0, false);
+    auto seg = [&](int32_t &off, int32_t &used, int nt, int kt) { take(off, used, nt * kt * BS); };
+    // ---- the weight stream of one rollout step
+    if (head) {
+        seg(o.dec_goal0.w[0], u.dec_goal0.w[0], 2, DT);
+        seg(o.dec_goal0.w[1], u.dec_goal0.w[1], 2, 2);
+        seg(o.dec_goal2.w[0], u.dec_goal2.w[0], GT, 2);
+        seg(o.lg_goals.w[0], u.lg_goals.w[0], GT, GT);
+        seg(o.g_goal.heads, u.g_goal.heads, 1, GT);
+        seg(o.g_goal.out, u.g_goal.out, GT, 1);
+        seg(o.lg_goals.w[1], u.lg_goals.w[1], GT, GT);
     }
-    lin(L.off.prior2, L.used.prior2, 2, 2, 0, 0, false);
-    lin(L.off.prior_ml, L.used.prior_ml, zt2, 2, 0, 0, false);
-    lin(L.off.enc0, L.used.enc0, 2, 2, 2, 0, dag);
-    lin(L.off.enc2, L.used.enc2, 2, 2, 0, 0, false);
-    lin(L.off.enc_ml, L.used.enc_ml, zt2, 2, 0, 0, false);
-    raw(L.off.dec_logvar_w, L.used.dec_logvar_w, L.off.dec_logvar_b, L.used.dec_logvar_b, 128, 2);
-    lin(L.off.dec2, L.used.dec2, 2, 2, 0, 0, false);
+    seg(o.prior0.w[0], u.prior0.w[0], 2, 2);
+    seg(o.prior2.w[0], u.prior2.w[0], 2, 2);
+    seg(o.prior_ml.w[0], u.prior_ml.w[0], zt2, 2);
+    seg(o.phi_z0.w[0], u.phi_z0.w[0], 2, (zd + 31) / 32);
+    seg(o.phi_z2.w[0], u.phi_z2.w[0], 2, 2);
+    if (dag) {
+        seg(o.dec0.w[0], u.dec0.w[0], 2, DT);
+        seg(o.dec0.w[1], u.dec0.w[1], 2, 2);
+        seg(o.dec0.w[2], u.dec0.w[2], 2, 2);
+    } else {
+        seg(o.dec0.w[0], u.dec0.w[0], 2, 2);
+        seg(o.dec0.w[1], u.dec0.w[1], 2, 2);
+    }
+    seg(o.dec2.w[0], u.dec2.w[0], 2, 2);
+    seg(o.phi_x2.w[0], u.phi_x2.w[0], 2, 2);
     for (int l = 0; l < nl; ++l) {
         const int kx = l == 0 ? 4 : 2;
-        lin(L.off.gru[l].r, L.used.gru[l].r, 2, kx, 2, 0, false);
-        lin(L.off.gru[l].z, L.used.gru[l].z, 2, kx, 2, 0, false);
-        lin(L.off.gru[l].ni, L.used.gru[l].ni, 2, kx, 0, 0, false);
-        lin(L.off.gru[l].nh, L.used.gru[l].nh, 2, 2, 0, 0, false);
+        if (bf) {       // two dense layers with six output tiles: r.w[0] = [n | r | z] rows of W_ih, r.w[1] = [r | z | n] rows of W_hh
+            seg(o.gru[l].r.w[0], u.gru[l].r.w[0], 6, kx);
+            seg(o.gru[l].r.w[1], u.gru[l].r.w[1], 6, 2);
+        } else {
+            seg(o.gru[l].nh.w[0], u.gru[l].nh.w[0], 2, 2);
+            seg(o.gru[l].r.w[0], u.gru[l].r.w[0], 2, kx);
+            seg(o.gru[l].r.w[1], u.gru[l].r.w[1], 2, 2);
+            seg(o.gru[l].ni.w[0], u.gru[l].ni.w[0], 2, kx);
+            seg(o.gru[l].z.w[0], u.gru[l].z.w[0], 2, kx);
+            seg(o.gru[l].z.w[1], u.gru[l].z.w[1], 2, 2);
+        }
     }
     if (graph) {
-        graphnet(L.off.g_hid, L.used.g_hid, 2, 2);
-        lin(L.off.blend, L.used.blend, 2, 2, 2, 0, false);
+        seg(o.g_hid.heads, u.g_hid.heads, 1, 2);
+        seg(o.g_hid.out, u.g_hid.out, 2, 1);
+        seg(o.blend.w[0], u.blend.w[0], 2, 2);
+        seg(o.blend.w[1], u.blend.w[1], 2, 2);
     }
+    // ---- teacher-forced pass only (forward_v2.hip)
+    seg(o.enc0.w[0], u.enc0.w[0], 2, 2);
+    seg(o.enc0.w[1], u.enc0.w[1], 2, 2);
+    seg(o.enc2.w[0], u.enc2.w[0], 2, 2);
+    seg(o.enc_ml.w[0], u.enc_ml.w[0], zt2, 2);
+    // ---- vectors: bias [nt*32] (+ one-hot table [GP][nt*32]) per dense layer, in the order above
+    auto vec = [&](V2Lin &lo, V2Lin &lu, int nt, bool gather) {
+        lo.gather = -1;
+        take(lo.bias, lu.bias, nt * 32);
+        if (gather) take(lo.gather, lu.gather, GP * nt * 32);
+    };
+    auto gvec = [&](V2Gat &go, V2Gat &gu, int nt) {
+        take(go.fold, gu.fold, 64);
+        if (gm != 2) take(go.fold_out, gu.fold_out, 64);
+        take(go.bn, gu.bn, 2 * nt * 32);
+    };
     if (head) {
-        lin(L.off.dec_goal0, L.used.dec_goal0, 2, DT, 2, 0, true);
-        lin(L.off.dec_goal2, L.used.dec_goal2, GT, 2, 0, 0, false);
-        graphnet(L.off.g_goal, L.used.g_goal, GT, GT);
-        lin(L.off.lg_goals, L.used.lg_goals, GT, GT, GT, 0, false);
+        vec(o.dec_goal0, u.dec_goal0, 2, true);
+        vec(o.dec_goal2, u.dec_goal2, GT, false);
+        vec(o.lg_goals, u.lg_goals, GT, false);
+        gvec(o.g_goal, u.g_goal, GT);
     }
+    vec(o.prior0, u.prior0, 2, dag);
+    vec(o.prior2, u.prior2, 2, false);
+    vec(o.prior_ml, u.prior_ml, zt2, false);
+    vec(o.phi_z0, u.phi_z0, 2, false);
+    vec(o.phi_z2, u.phi_z2, 2, false);
+    vec(o.dec0, u.dec0, 2, dag);
+    vec(o.dec2, u.dec2, 2, false);
+    vec(o.phi_x2, u.phi_x2, 2, false);
+    for (int l = 0; l < nl; ++l) {
+        vec(o.gru[l].nh, u.gru[l].nh, 2, false);
+        vec(o.gru[l].r, u.gru[l].r, 2, false);
+        vec(o.gru[l].ni, u.gru[l].ni, 2, false);
+        vec(o.gru[l].z, u.gru[l].z, 2, false);
+    }
+    if (graph) {
+        gvec(o.g_hid, u.g_hid, 2);
+        vec(o.blend, u.blend, 2, false);
+    }
+    vec(o.enc0, u.enc0, 2, dag);
+    vec(o.enc2, u.enc2, 2, false);
+    vec(o.enc_ml, u.enc_ml, zt2, false);
+    take(o.phi_x0_w, u.phi_x0_w, 128);
+    take(o.phi_x0_b, u.phi_x0_b, 64);
+    take(o.dec_mean_w, u.dec_mean_w, 128);
+    take(o.dec_mean_b, u.dec_mean_b, 2);
+    take(o.dec_logvar_w, u.dec_logvar_w, 128);
+    take(o.dec_logvar_b, u.dec_logvar_b, 2);
     L.total = (cur + 3) & ~3;
     return L;
 }

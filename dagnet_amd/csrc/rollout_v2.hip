@@ -29,8 +29,11 @@ namespace v2 {
 // GM: 1 = GAT (4 heads x 8), 2 = GCN (graph_hid <= 32).
 // BF: dense products on the bf16 matrix pipe (three bf16 terms per fp32 value, v2_common.h mm<..., BF>); weights from the
 // split-bf16 region of the model (params_v2.h).
+#ifndef DN_V2_OCC
+#define DN_V2_OCC 2       // waves per SIMD the register budget is cut for
+#endif
 template <int MODEL, int NL, int ZD, int GM, bool BF>
-__global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
+__global__ __launch_bounds__(64, DN_V2_OCC) void rollout_v2_kernel(const V2Weights *__restrict__ Wp, const V2Run R) {
     // segment offsets are compile-time constants of the instantiation (params_v2.h v2_layout; checked against the packer's
     // table when the model is created): immediates, no table loads on the critical path, no SGPRs held for them
     // (model 3 keeps the packer's table: its one-hot tables have g_dim rows, in the hundreds)
@@ -41,7 +44,8 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
     // DAG-Net: hidden state parked in LDS while the goal head needs the registers ([tile][reg][lane], conflict free)
     // also (NL == 2): the top layer's state is parked while GRU layer 0 runs (its 4 input tiles + 2 state tiles + gate
     // temporaries do not fit beside it; the compiler would spill ~140 registers to scratch memory instead)
-    __shared__ float stash[(MODEL == 2 || MODEL == 4) ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
+    // split-bf16 kernels: every layer's state has its slot (a GRU layer parks its state there while it multiplies its inputs)
+    __shared__ float stash[(MODEL == 2 || MODEL == 4 || BF) ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
     __shared__ float gbias[NL * GRU_BIAS_FLOATS];      // GRU gate biases (v2_common.h gru_bias_to_lds)
     float *pos = xch + 128;                 // [32][2] current absolute positions of the tile rows
     const int lane = threadIdx.x, lh = lane >> 5, lc = lane & 31;
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
         {
             T16 px[2];
             start<2>(px, wp, W.phi_x2, 0, lh);
-            pre = mm<2, 2, false, BF>(px, wp, W.phi_x2.w[0], ta, lane, pre, W.gru[0].nh.w[0]);
+            pre = mm<2, 2, false, BF>(px, wp, W.phi_x2.w[0], ta, lane, pre, BF ? W.gru[0].r.w[0] : W.gru[0].nh.w[0]);
             activate<1, 2>(px);
             xin[0] = px[0]; xin[1] = px[1]; xin[2] = pz[0]; xin[3] = pz[1];
         }
@@ -473,13 +477,15 @@ __global__ __launch_bounds__(64, 2) void rollout_v2_kernel(const V2Weights *__re
 #pragma unroll
                 for (int r = 0; r < 16; ++r) stash[(nt * 16 + r) * 64 + lane] = h[1][nt][r];
         }
-        pre = gru<4, true, BF>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? W.gru[1].nh.w[0] : after_gru, gbias);
+        // (slot of h[l] in the stash: tiles 2l, 2l+1 counted from the top layer down - the top layer's state sits at 0)
+        pre = gru<4, true, BF>(xin, h[0], wp, W.gru[0], lane, pre, NL == 2 ? (BF ? W.gru[1].r.w[0] : W.gru[1].nh.w[0]) : after_gru, gbias,
+                               BF ? stash + (NL == 2 ? 2 * 16 * 64 : 0) : nullptr);
         if constexpr (NL == 2) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[1][nt][r] = stash[(nt * 16 + r) * 64 + lane];
-            pre = gru<2, true, BF>(h[0], h[1], wp, W.gru[1], lane, pre, after_gru, gbias + GRU_BIAS_FLOATS);
+            pre = gru<2, true, BF>(h[0], h[1], wp, W.gru[1], lane, pre, after_gru, gbias + GRU_BIAS_FLOATS, BF ? stash : nullptr);
         }
         PH(8);
         // -------------------------------------------------------------------- graph refinement of h[-1]
@@ -537,11 +543,15 @@ static hipError_t launch_one(const V2Weights *d_w, const V2Run &r, hipStream_t s
 // (model, GRU layers, z_dim, graph) combinations with an instantiation: the shapes of the shipped checkpoints
 // (basketball: DAG-Net L2/Z32, A-VRNN L1/Z32, VRNN L2/Z32; SDD: A-VRNN L1/Z16, VRNN L2/Z16) plus A-VRNN L2/Z32, DAG-Net L1/Z32 and L2/Z16, model 3
 // (goal head outside) and the GCN variants of the graph models.  graph: 0 none (VRNN), 1 GAT, 2 GCN.
+#ifdef DN_V2_ONLY      // kernel experiments (tools/variants.sh): the DAG-Net / A-VRNN / VRNN basketball instantiations only
+#define V2_INSTANCES V2_CASE(2, 2, 32, 1) V2_CASE(1, 1, 32, 1) V2_CASE(0, 2, 32, 1)
+#else
 #define V2_INSTANCES                                                                                                   \
     V2_CASE(2, 2, 32, 1) V2_CASE(1, 1, 32, 1) V2_CASE(0, 2, 32, 1) V2_CASE(1, 1, 16, 1) V2_CASE(0, 2, 16, 1) V2_CASE(1, 2, 32, 1) \
     V2_CASE(3, 2, 32, 1) V2_CASE(4, 2, 32, 1) V2_CASE(2, 2, 32, 2) V2_CASE(1, 1, 32, 2) V2_CASE(1, 1, 16, 2) V2_CASE(1, 2, 32, 2) \
     V2_CASE(2, 1, 32, 1) V2_CASE(2, 2, 16, 1) V2_CASE(4, 1, 32, 1) V2_CASE(4, 2, 16, 1) V2_CASE(3, 1, 32, 1) V2_CASE(3, 2, 16, 1) \
     V2_CASE(2, 1, 32, 2) V2_CASE(2, 2, 16, 2)
+#endif
 
 // returns hipErrorInvalidValue when the combination has no instantiation; d_w: DEVICE pointer to the model's V2Weights table
 #if DN_V2_BF

@@ -89,6 +89,11 @@ __device__ __forceinline__ void zero(T16 (&x)[N]) {
 #ifndef V2_BF_DEPTH
 #define V2_BF_DEPTH 2
 #endif
+#ifdef DN_V2_NOFENCE      // experiment: leave the order of splits, loads and MFMAs of the split-bf16 products to the compiler
+#define V2_FENCE()
+#else
+#define V2_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 struct WBlk {
     float4 v[3 * V2_BF_DEPTH > 4 ? 3 * V2_BF_DEPTH : 4];
 };
@@ -122,18 +127,24 @@ __device__ __forceinline__ bf16x8 as_bf8(float4 v) { return __builtin_bit_cast(b
 struct XSplit {
     float4 t[3];
 };
+// The values are read through an opaque copy: left alone, the compiler recognises the split of a tile that several products
+// read (h, phi_z, the GRU's inputs) as a common subexpression and keeps all 24 registers per tile alive from the first use to
+// the last - the register file does not have them (it spilled ~100 registers per lane); a split is 38 instructions per half tile.
 __device__ __forceinline__ void split3(const T16 &x, int p, XSplit &s) {
     unsigned pk[3][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float v0 = x[8 * p + 2 * j], v1 = x[8 * p + 2 * j + 1];
+        asm volatile("" : "+v"(v0), "+v"(v1));
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const unsigned u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
             pk[t][j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);      // {hi16(v1), hi16(v0)}
-            if (t < 2) {
-                v0 -= __uint_as_float(u0 & 0xffff0000u);
-                v1 -= __uint_as_float(u1 & 0xffff0000u);
+            if (t < 2) {       // one v_pk_add_f32 for the pair (tools/ubench/split_forms.hip: 508 against 556 clocks per tile)
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                const f2 v = f2{v0, v1} - f2{__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)};
+                v0 = v.x;
+                v1 = v.y;
             }
         }
     }
@@ -163,7 +174,7 @@ __device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, cons
         for (int i = 0; i < NH; ++i) {
             const int kt = i / (2 * NT), p = (i / NT) % 2, nt = i % NT, d = i % D;
             if (nt == 0) split3(x[kt], p, xs);
-            __builtin_amdgcn_sched_barrier(0);
+            V2_FENCE();
             const float4 w0 = q.v[3 * d], w1 = q.v[3 * d + 1], w2 = q.v[3 * d + 2];
             // smallest products first: W term tw with x terms 2 - tw .. 0
             if (!TR) {
@@ -181,7 +192,7 @@ __device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, cons
                 out[nt] = MFMA_BF(as_bf8(xs.t[1]), as_bf8(w0), out[nt]);
                 out[nt] = MFMA_BF(as_bf8(xs.t[0]), as_bf8(w0), out[nt]);
             }
-            __builtin_amdgcn_sched_barrier(0);
+            V2_FENCE();
             // the slot just consumed takes half block i + D of this call, or the next consumer's
             wload_half(q, d, wp, i + D < NH ? off + (i + D) * V2_HALF_BF3 : next_off + (i + D - NH) * V2_HALF_BF3, lane);
         }
@@ -568,7 +579,7 @@ __device__ __forceinline__ void gru_bias_to_lds(float *dst, const WBuf &wp, cons
 // LB: the layer's biases are in LDS at lb (gru_bias_to_lds); else they are loaded from the weight buffer.
 template <int KX, bool LB = false, bool BF = false>
 __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBuf &wp, const V2Gru &Gw, int lane, WBlk pre,
-                                    int next_off, const float *lb = nullptr) {
+                                    int next_off, const float *lb = nullptr, float *park = nullptr) {
     const int lh = lane >> 5;
     auto bias4 = [&](int gate, int goff, int f) -> float4 {      // 4 consecutive features f + 4*lh .. of gate `gate`
         if constexpr (LB) return *reinterpret_cast<const float4 *>(lb + gate * 64 + f + 4 * lh);
@@ -583,6 +594,44 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
             acc[4 * a + 0] = b.x; acc[4 * a + 1] = b.y; acc[4 * a + 2] = b.z; acc[4 * a + 3] = b.w;
         }
     };
+    if constexpr (BF) {
+        // split-bf16 products: the GRU as two dense layers with six output tiles each, so that every input tile is split once -
+        //   X phase: [ni | r | z] += W_ih x      (g[0..5], stream Gw.r.w[0]: rows n, r, z of weight_ih, [kt][p][6 tiles])
+        //   H phase: [r | z | nh] += W_hh h      (g[2..7], stream Gw.r.w[1]: rows r, z, n of weight_hh)
+        // h is not read in the X phase: with `park` (16 x 64 floats per tile of LDS, [tile][reg][lane]) it waits there.
+        T16 g[8];
+        init(g[0], 2, Gw.ni.bias, 0);
+        init(g[1], 2, Gw.ni.bias, 1);
+        init(g[2], 1, Gw.r.bias, 0);
+        init(g[3], 1, Gw.r.bias, 1);
+        init(g[4], 3, Gw.z.bias, 0);
+        init(g[5], 3, Gw.z.bias, 1);
+        if (park) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) park[(nt * 16 + r) * 64 + lane] = h[nt][r];
+        }
+        pre = mm<6, KX, false, true>(reinterpret_cast<T16(&)[6]>(g[0]), wp, Gw.r.w[0], xin, lane, pre, Gw.r.w[1]);
+        if (park) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) h[nt][r] = park[(nt * 16 + r) * 64 + lane];
+        }
+        init(g[6], 0, Gw.nh.bias, 0);
+        init(g[7], 0, Gw.nh.bias, 1);
+        pre = mm<6, 2, false, true>(reinterpret_cast<T16(&)[6]>(g[2]), wp, Gw.r.w[1], h, lane, pre, next_off);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float ng = tanh2(g[nt][r] + sigm2(g[2 + nt][r]) * g[6 + nt][r]);
+                const float zg = sigm2(g[4 + nt][r]);
+                h[nt][r] = zg * (h[nt][r] - ng) + ng;        // (1 - z) n + z h
+            }
+        return pre;
+    }
     T16 hn[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {

@@ -573,7 +573,10 @@ def main():
             launch_flop /= n_chunks
         achieved = launch_flop / (kernel_ms * 1e-3) / 1e12
         info = model.hip_plan(dev, np.ascontiguousarray(plan_sp - plan_sp[0]), K).info()
-        split_bf16 = "wide goal head" in info["sample_kernel"] and not os.environ.get("DAGNET_NO_BF16X3")
+        # the dense products of the register-resident kernels and of the wide goal head run on the bf16 matrix pipe (three bf16
+        # terms per fp32 value, six products) unless switched off; the generic kernels always use fp32 MFMAs
+        from dagnet_amd import _ops
+        split_bf16 = ("wide goal head" in info["sample_kernel"] or "register-resident" in info["sample_kernel"]) and bool(_ops.set_fused(-1) & 8)
         peak = PEAK_SPLIT_BF16_TFLOPS if split_bf16 else PEAK_FP32_MATRIX_TFLOPS
         line = {
             "metric": "sampled trajectories/sec (best-of-20 rollout)", "value": value, "unit": "trajectories/s",
@@ -596,6 +599,21 @@ def main():
             "forward_obs_ms": fwd_ms, "steps_requested": steps_requested, "warmup_requested": warmup_requested,
             "ade": float(tot[0] / (tot[2] * T)), "fde": float(tot[1] / tot[2]),
         }
+        if split_bf16 and n_chunks == 1 and not opt.no_reference_loop:
+            # the same launch with the products on fp32 MFMAs (untimed leg, 2 launches): the fp32-matrix roofline of round 2
+            _ops.set_fused(_ops.set_fused(-1) & ~8)
+            try:
+                step(0, False)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                step(1, False)
+                torch.cuda.synchronize()
+                f32_ms = (time.perf_counter() - t0) * 1e3
+            finally:
+                _ops.set_fused(-1)
+            line["roofline"]["fp32_mfma"] = {"ms_per_step": f32_ms, "achieved": launch_flop / (f32_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS,
+                                             "unit": "TFLOP/s", "frac": launch_flop / (f32_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
+                                             "note": "the same step with DAGNET_NO_BF16X3 semantics (whole step incl. metrics, wall clock)"}
         if n_chunks == 1 and not opt.no_reference_loop:
             # the reference's evaluation loop AS WRITTEN (models/dagnet/evaluate_bsk.py:113-114): K separate sample() calls
             torch.cuda.synchronize()

@@ -141,7 +141,7 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
 
 def set_fused(mask: int) -> int:
     """Select the fused kernels (bit 0 GRU layer forward, 1 dense blocks forward, 2 dense blocks backward, 3 split-bf16 products in
-    the wide GEMM; < 0: default).
+    the wide GEMM and in the register-resident rollout kernels; < 0: default).
     -> the previous mask."""
     return int(_lib().dagnet_op_set_fused(int(mask)))
 

@@ -844,7 +844,7 @@ std::string v2_check_layout(const V2Weights &W, int base, int total, int model_c
 // C ABI
 // ---------------------------------------------------------------------------------------------
 extern "C" const char *dagnet_last_error(void) { return g_err; }
-extern "C" const char *dagnet_version(void) { return "dagnet_hip 0.1 (gfx950, fp32 MFMA 32x32x2)"; }
+extern "C" const char *dagnet_version(void) { return "dagnet_hip 0.3 (gfx950, split-bf16 32x32x16 + fp32 32x32x2 MFMA)"; }
 
 extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor *tensors, int32_t n_tensors, dagnet_model **out) {
     if (!cfg || !out || (!tensors && n_tensors > 0)) return fail(DAGNET_ERR_INVALID, "null argument");

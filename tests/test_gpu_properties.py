@@ -496,3 +496,79 @@ def test_chunked_best_of_k_equals_unchunked():
     t1 = best_of_k_chunked(m, a, K, h, obs[-1], g0, gt, sse, 3, seed=5).cpu()
     t2 = best_of_k_chunked(m, a, K, h, obs[-1], g0, gt, sse, 3, seed=5).cpu()
     assert torch.equal(t1, t2) and torch.isfinite(t1).all()
+
+
+def _scene_rows(sizes):
+    return torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+
+
+@pytest.mark.parametrize("kind,kw,n_max", [("vrnn", dict(n_layers=2), 10), ("avrnn", dict(n_layers=1), 10), ("avrnn", dict(n_layers=2, graph_model="gcn"), 10),
+                                           ("dagnet", dict(n_layers=2), 10), ("dagnet", dict(n_layers=1), 10), ("dagnet", dict(n_layers=2, graph_model="gcn"), 10),
+                                           ("dagnet", dict(n_layers=2, **KNN), 20)])
+def test_rollout_split_bf16_matches_fp32_products(kind, kw, n_max):
+    """The rollout kernels' dense products on the bf16 matrix pipe (three bf16 terms per fp32 value, six products: v2_common.h
+    mm<..., BF>, the default) against the same kernels on fp32 MFMAs (bit 3 of dagnet_op_set_fused off), in-kernel noise, 40 steps:
+    trajectories to fp32 noise; DAG-Net: the drawn goals equal except near-ties, which change the whole scene's future."""
+    from dagnet_amd import _ops
+    a, m, _ = _model(kind, n_max=n_max, seed=11, **kw)
+    sizes = [int(v) for v in np.random.default_rng(7).integers(1, n_max + 1, size=150)]
+    N, K, T = sum(sizes), 4, 40
+    batch = [t.to(DEV) for t in syn.make_batch(sizes, 10, T, 4)]
+    h = (syn.uniform_noise(5, "h0", (a.n_layers, N, 64)) - 0.5).to(DEV)
+    out = {}
+    before = _ops.set_fused(-1)
+    try:
+        for mask in (15, 7):
+            _ops.set_fused(mask)
+            extra = dict(return_goals=True) if kind == "dagnet" else {}
+            out[mask] = _sample_k(kind, m, K, T, h, batch, seed=33, **extra)
+    finally:
+        _ops.set_fused(before)
+    if kind != "dagnet":
+        assert not torch.equal(out[15], out[7]), "the switch did not change the products: both runs took the same kernel"
+        tol = 1e-4 + 1e-4 * out[7].abs()
+        assert bool(((out[15] - out[7]).abs() <= tol).all()), float((out[15] - out[7]).abs().max())
+        return
+    (s_b, g_b), (s_f, g_f) = out[15], out[7]
+    rows = _scene_rows(sizes).to(DEV)
+    eq = (g_b == g_f).all(dim=1).float()                                         # [K, N]: the row drew the same goals at every step
+    scene_ok = torch.ones((K, len(sizes)), device=DEV).scatter_reduce(1, rows.expand(K, N), eq, "amin")
+    ok = scene_ok.gather(1, rows.expand(K, N)).bool()                            # rows whose whole scene drew the same goals
+    assert ok.float().mean() > 0.97, float(ok.float().mean())
+    d = (s_b - s_f).abs().amax(dim=-1).amax(dim=1)                               # [K, N]
+    assert float(d[ok].max()) < 2e-4, float(d[ok].max())
+
+
+def test_split_bf16_truncation_bias_over_40_steps():
+    """The bf16 matrix pipe truncates its internal sums toward zero (csrc/gemm_f32.hip: -2.4e-6 relative at K = 1920 when every
+    product has the same sign).  Worst case for the rollout: a VRNN whose weights, biases, state and noise are all positive, so
+    that every product of every layer has the same sign for 40 steps.  Against the oracle in fp64 the split-bf16 kernel must stay
+    within the parity tolerance, and its error and signed bias are printed next to the fp32 MFMA kernel's."""
+    from dagnet_amd import _ops
+    from oracle import dagnet_oracle as orc
+    a = syn.make_args(n_layers=2)
+    m = dagnet_amd.VRNN(a)
+    sd = {k: v.abs() * (0.35 if v.ndim == 2 else 1.0) for k, v in syn.random_state_dict(m, 3).items()}
+    m.load_state_dict(sd)
+    m = m.to(DEV).eval()
+    cfg = orc.make_cfg(n_max_agents=10, **{k: getattr(a, k) for k in ("x_dim", "h_dim", "z_dim", "rnn_dim", "n_layers", "g_dim", "graph_model",
+                                                                        "graph_hid", "adjacency_type", "top_k_neigh", "sigma", "alpha", "n_heads")})
+    N, T = 96, 40
+    h = syn.uniform_noise(1, "h0", (2, N, 64)) * 0.5
+    eps = syn.uniform_noise(2, "eps", (T, N, a.z_dim))
+    with torch.no_grad():
+        want = orc.vrnn_sample({k: v.double() for k, v in sd.items()}, cfg, T, h.double(), eps.double())
+    assert float(want.min()) > 0
+    got = {}
+    before = _ops.set_fused(-1)
+    try:
+        for mask in (15, 7):
+            _ops.set_fused(mask)
+            got[mask] = m.sample(T, h.to(DEV), eps=eps.to(DEV)).cpu().double()
+    finally:
+        _ops.set_fused(before)
+    rel = {k: (v - want) / want for k, v in got.items()}
+    print(f"\n40 same-sign steps, relative to fp64: split bf16 max {float(rel[15].abs().max()):.2e} bias {float(rel[15].mean()):+.2e}; "
+          f"fp32 MFMA max {float(rel[7].abs().max()):.2e} bias {float(rel[7].mean()):+.2e}")
+    assert float(rel[15].abs().max()) < 2e-5
+    assert abs(float(rel[15].mean())) < 5e-6

@@ -225,6 +225,11 @@ def bench_train(opt, wl, rank, world, dev, dist):
     training.attach_grad_arena(model, optim)
 
     frac = 1.0 / world                          # KLD / NLL are means over the rows of the shard, CE is a sum
+    if opt.sync_bn:
+        _ops.set_sync_batchnorm("dist")
+        _ops.BN_SYNC.rows_all = n_rows * world
+        if world > 1:
+            opt.no_graph = True
     eps_all = torch.empty((T - 1, n_rows, a.z_dim), dtype=torch.float32, device=dev)
 
     def loss_fn(m, eps):
@@ -265,15 +270,30 @@ def bench_train(opt, wl, rank, world, dev, dist):
         return
     flop = train_flops_per_row_step(a, wl["agents"], 2 * wl["agents"]) * n_rows * (T - 1)
     achieved = flop / (dt / opt.steps) / 1e12
+    # HBM-side bytes of one optimizer step, summed over all its kernels, from the newest committed counter passes of this workload
+    # (tools/train_pmc.sh -> profiles/*_pmc.json); the tape the backward pass cannot avoid is ~150 GB at this size
+    traffic = None
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+        try:
+            traffic = json.load(open(path))[opt.workload]["step"]["traffic_bytes_per_step"]
+            break
+        except (OSError, ValueError, KeyError):
+            continue
+    hbm = None if traffic is None else traffic / (dt / opt.steps) / 1e9
     line = {
         "metric": "training trajectories/sec (one optimizer step, teacher-forced 50-step sequences)",
         "value": n_rows * world * opt.steps / dt, "unit": "trajectories/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
         "ms_per_step": dt / opt.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": opt.workload, "model": "dagnet", "scenes_per_gpu": S, "agents_per_scene": wl["agents"], "seq_len": T,
-                   "rows_per_gpu": n_rows, "parallelism": f"scenes sharded x{world}, one all-reduce of 184 350 fp32 gradients per step"},
+                   "rows_per_gpu": n_rows, "batchnorm": "synchronised over all ranks" if opt.sync_bn else "per-rank statistics",
+                   "hip_graph": not opt.no_graph,
+                   "parallelism": f"scenes sharded x{world}, one all-reduce of 184 350 fp32 gradients per step"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
+                     "hbm": None if hbm is None else {"achieved": hbm, "peak": 8000.0, "unit": "GB/s", "frac": hbm / 8000.0,
+                                                      "note": "all kernels of the step: (2 x FETCH_SIZE + WRITE_SIZE) / step time"},
                      "kernel": "layer-by-layer operators (gemm_f32.hip + train_ops.hip): bound by streaming activations, see DESIGN.md 4.5"},
         "loss": float(loss.detach()),
     }
@@ -422,6 +442,9 @@ def main():
                     help="skip the untimed reference_loop_ms leg (K separate sample() calls): profiling runs, so that the per-kernel "
                          "averages cover only the launches of the timed region")
     ap.add_argument("--no-graph", action="store_true", help="training workloads: issue every launch from the host instead of replaying a hipGraph")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="training workloads: BatchNorm statistics over the rows of all ranks (the reference's whole-batch BatchNorm); "
+                         "with more than one rank the step runs eagerly (its collectives are not captured into the hipGraph)")
     ap.add_argument("--rehearse", action="store_true", help="launcher + process group + reductions on the CPU (gloo), no GPU work")
     opt = ap.parse_args()
     wl = WORKLOADS[opt.workload]

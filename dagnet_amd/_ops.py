@@ -25,6 +25,7 @@ OP_EXPORTS = (
     "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_mlp_chain_fwd", "dagnet_op_mlp2_bwd", "dagnet_op_linear_pieces_bwd", "dagnet_op_set_fused", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd", "dagnet_op_softmax_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
+    "dagnet_op_bn_moments", "dagnet_op_bn_merge", "dagnet_op_bn_apply", "dagnet_op_bn_bwd_sums", "dagnet_op_bn_bwd_apply",
     "dagnet_op_gat_attn_fwd", "dagnet_op_gat_attn_bwd", "dagnet_op_adj_matmul", "dagnet_op_disposition", "dagnet_op_sumsq",
     "dagnet_op_adam",
 )
@@ -77,6 +78,11 @@ def _lib():
         lib.dagnet_op_colsum_static.argtypes = [i64, i32, vp, i64, vp, i32, vp]
         lib.dagnet_op_bn_fwd.argtypes = [i64, i32, vp, i64, vp, vp, f32, f32, i32, vp, i64, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_bn_bwd.argtypes = [i64, i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, vp, i64, vp, vp, i32, vp, vp, vp]
+        lib.dagnet_op_bn_moments.argtypes = [i64, i32, vp, i64, vp, vp, vp, vp]
+        lib.dagnet_op_bn_merge.argtypes = [i32, i32, vp, f32, f32, vp, vp, vp, vp, vp]
+        lib.dagnet_op_bn_apply.argtypes = [i64, i32, vp, i64, vp, vp, vp, i32, vp, i64, vp]
+        lib.dagnet_op_bn_bwd_sums.argtypes = [i64, i32, vp, i64, vp, vp, i64, vp, i64, i32, vp, vp, vp]
+        lib.dagnet_op_bn_bwd_apply.argtypes = [i64, i64, i32, vp, i64, vp, vp, vp, i64, vp, i64, i32, vp, vp, i64, vp]
         lib.dagnet_op_gat_attn_fwd.argtypes = [vp, vp, i64, vp, i64, vp, i32, i32, f32, i32, vp, i64, vp]
         lib.dagnet_op_gat_attn_bwd.argtypes = [vp, vp, i64, vp, i64, vp, i32, i32, f32, i32, vp, i64, vp, i64, vp, i64, vp, vp]
         lib.dagnet_op_adj_matmul.argtypes = [vp, i32, vp, i64, vp, i64, vp, i32, vp, i64, vp]
@@ -1299,9 +1305,115 @@ def disposition(plan, pos: torch.Tensor, D: int) -> torch.Tensor:
     return out
 
 
+class BnSync:
+    """Who shares BatchNorm statistics in train mode.  The reference's nn.BatchNorm1d normalises with the mean / variance of ALL
+    rows of the batch (gat_model.py:21, gcn_model.py:16,18); with the scenes sharded over ranks that takes an exchange:
+      * ``mode = "dist"``: the ranks of the default torch.distributed group - one all-gather of [3N] moments in the forward pass and
+        one all-reduce of [2N] sums in the backward pass per BatchNorm call (RCCL; collectives cannot be captured into the training
+        step's hipGraph by this code: run the step eagerly);
+      * ``mode = "virtual"``: ``bounds`` cuts the rows of ONE process's batch into shards that go through the same staged kernels
+        (moments per shard -> merge -> apply; sums per shard -> add -> apply) - how tests check the staged path against the
+        whole-batch goldens on one GPU;
+      * ``mode = None`` (default): per-process statistics (BnFn), the documented deviation under data parallelism."""
+    mode = None
+    bounds = None
+    rows_all = None      # "dist": rows of the whole batch over all ranks when the caller knows it (else one blocking all-reduce per call)
+
+
+BN_SYNC = BnSync()
+
+
+def set_sync_batchnorm(mode, bounds=None):
+    """mode: None | "dist" | "virtual" (bounds: row boundaries [0, m1, ..., M] of the virtual shards).  -> the previous (mode, bounds)."""
+    prev = (BN_SYNC.mode, BN_SYNC.bounds)
+    if mode not in (None, "dist", "virtual"):
+        raise ValueError("sync BatchNorm mode must be None, 'dist' or 'virtual'")
+    BN_SYNC.mode, BN_SYNC.bounds = mode, (list(bounds) if bounds is not None else None)
+    return prev
+
+
+class SyncBnFn(torch.autograd.Function):
+    """nn.BatchNorm1d in train mode with statistics over the rows of all shards (BnSync), + optional tanh."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, run_mean, run_var, eps, momentum, tanh_out):
+        lib, st = _lib(), _stream(x.device)
+        M, N = x.shape
+        ctx.slot = POOL.site()
+        y = POOL.at(ctx.slot, "y", (M, N), x)
+        stat = POOL.at(ctx.slot, "stat", (2 * N,), x)
+        tmp = POOL.at(ctx.slot, "tmp", (2 * N,), x)
+        total = POOL.at(ctx.slot, "total", (1,), x)
+        (xp, ldx), (yp, ldy) = _m(x), _m(y)
+        if BN_SYNC.mode == "virtual":
+            b = BN_SYNC.bounds
+            assert b[0] == 0 and b[-1] == M, "virtual shard bounds must cover the batch"
+            parts = POOL.at(ctx.slot, "parts", ((len(b) - 1) * 3 * N,), x).view(len(b) - 1, 3 * N)      # (1-D: the pool pads matrix rows)
+            for k in range(len(b) - 1):
+                rows = b[k + 1] - b[k]
+                ws = _ws(x.device, lib.dagnet_op_col_workspace(max(rows, 1), N))
+                _check(lib.dagnet_op_bn_moments(rows, N, C.c_void_p(x.data_ptr() + 4 * b[k] * ldx), ldx, _p(parts[k]), _p(tmp), _p(ws), st))
+            ctx.shards = [(b[k], b[k + 1]) for k in range(len(b) - 1)]
+        else:
+            import torch.distributed as dist
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            mom = POOL.at(ctx.slot, "mom", (3 * N,), x)
+            ws = _ws(x.device, lib.dagnet_op_col_workspace(max(M, 1), N))
+            _check(lib.dagnet_op_bn_moments(M, N, xp, ldx, _p(mom), _p(tmp), _p(ws), st))
+            parts = POOL.at(ctx.slot, "parts", (world * 3 * N,), x).view(world, 3 * N)
+            ctx.Mtot = M
+            if world > 1:
+                dist.all_gather_into_tensor(parts.view(-1), mom)
+                if BN_SYNC.rows_all is not None:
+                    ctx.Mtot = int(BN_SYNC.rows_all)
+                else:
+                    cnt = torch.tensor([float(M)], dtype=torch.float64, device=x.device)
+                    dist.all_reduce(cnt)
+                    ctx.Mtot = int(cnt.item())
+            else:
+                parts[0].copy_(mom)
+            ctx.shards = [(0, M)]
+        _check(lib.dagnet_op_bn_merge(N, parts.shape[0], _p(parts), eps, momentum, _p(stat), _p(run_mean), _p(run_var), _p(total), st))
+        _check(lib.dagnet_op_bn_apply(M, N, xp, ldx, _p(stat), _p(gamma), _p(beta), int(tanh_out), yp, ldy, st))
+        ctx.save_for_backward(x, gamma, stat, y, parts)
+        ctx.tanh_out, ctx.virtual = tanh_out, BN_SYNC.mode == "virtual"
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, stat, y, parts = ctx.saved_tensors
+        lib, st = _lib(), _stream(x.device)
+        M, N = x.shape
+        dy = _rows(dy)
+        dx = POOL.at(ctx.slot, "dx", (M, N), x)
+        (xp, ldx), (gp, ldg), (yp, ldy), (dp, ldd) = _m(x), _m(dy), _m(y), _m(dx)
+        sums = POOL.at(ctx.slot, "sums", (len(ctx.shards) * 2 * N,), x).view(len(ctx.shards), 2 * N)
+        for k, (r0, r1) in enumerate(ctx.shards):
+            ws = _ws(x.device, lib.dagnet_op_col_workspace(max(r1 - r0, 1), N))
+            _check(lib.dagnet_op_bn_bwd_sums(r1 - r0, N, C.c_void_p(x.data_ptr() + 4 * r0 * ldx), ldx, _p(stat),
+                                             C.c_void_p(dy.data_ptr() + 4 * r0 * ldg), ldg, C.c_void_p(y.data_ptr() + 4 * r0 * ldy), ldy,
+                                             int(ctx.tanh_out), _p(sums[k]), _p(ws), st))
+        local = sums.sum(0) if len(ctx.shards) > 1 else sums[0]          # this process's share of dbeta | dgamma
+        dbeta, dgamma = local[:N].clone(), local[N:].clone()
+        tot_sums, Mtot = local, M
+        if not ctx.virtual:
+            import torch.distributed as dist
+            Mtot = ctx.Mtot
+            if dist.is_initialized() and dist.get_world_size() > 1:
+                tot_sums = local.clone()
+                dist.all_reduce(tot_sums)
+        tot_sums = tot_sums.contiguous()
+        for (r0, r1) in ctx.shards:
+            _check(lib.dagnet_op_bn_bwd_apply(r1 - r0, Mtot, N, C.c_void_p(x.data_ptr() + 4 * r0 * ldx), ldx, _p(stat), _p(gamma),
+                                              C.c_void_p(dy.data_ptr() + 4 * r0 * ldg), ldg, C.c_void_p(y.data_ptr() + 4 * r0 * ldy), ldy,
+                                              int(ctx.tanh_out), _p(tot_sums), C.c_void_p(dx.data_ptr() + 4 * r0 * ldd), ldd, st))
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
 def bn_train(bn: torch.nn.BatchNorm1d, x: torch.Tensor, tanh_out: bool) -> torch.Tensor:
     momentum = 0.1 if bn.momentum is None else bn.momentum
-    y = BnFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, tanh_out)
+    fn = SyncBnFn if BN_SYNC.mode is not None else BnFn
+    y = fn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, tanh_out)
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked += 1
     return y

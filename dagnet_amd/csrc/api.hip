@@ -2021,6 +2021,44 @@ extern "C" int dagnet_op_bn_bwd(int64_t M, int32_t N, const float *X, int64_t ld
     HIP_TRY(dn_t_bn_bwd(M, N, X, ldx, stat, gamma, dOut, ldd, Out, ldo, tanh_out, dX, ldg, dgamma, dbeta, accumulate, sums, workspace, OP_ST));
     return DAGNET_OK;
 }
+extern "C" hipError_t dn_t_bn_moments(int64_t, int, const float *, int64_t, float *, float *, float *, hipStream_t);
+extern "C" hipError_t dn_t_bn_merge(int, int, const float *, float, float, float *, float *, float *, float *, hipStream_t);
+extern "C" hipError_t dn_t_bn_apply(int64_t, int, const float *, int64_t, const float *, const float *, const float *, int, float *, int64_t, hipStream_t);
+extern "C" hipError_t dn_t_bn_bwd_sums(int64_t, int, const float *, int64_t, const float *, const float *, int64_t, const float *, int64_t, int,
+                                       float *, float *, hipStream_t);
+extern "C" hipError_t dn_t_bn_bwd_apply(int64_t, int64_t, int, const float *, int64_t, const float *, const float *, const float *, int64_t,
+                                        const float *, int64_t, int, const float *, float *, int64_t, hipStream_t);
+extern "C" int dagnet_op_bn_moments(int64_t M, int32_t N, const float *X, int64_t ldx, float *mom, float *tmp, float *workspace, void *stream) {
+    OP_NEED(M >= 0 && N >= 1 && mom && tmp && workspace && (M == 0 || X), "bad argument");
+    HIP_TRY(dn_t_bn_moments(M, N, X, ldx, mom, tmp, workspace, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_bn_merge(int32_t N, int32_t n_parts, const float *parts, float eps, float momentum, float *stat, float *run_mean,
+                                  float *run_var, float *total, void *stream) {
+    OP_NEED(N >= 1 && n_parts >= 1 && parts && stat, "bad argument");
+    OP_NEED((run_mean == nullptr) == (run_var == nullptr), "running_mean and running_var go together");
+    HIP_TRY(dn_t_bn_merge(N, n_parts, parts, eps, momentum, stat, run_mean, run_var, total, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_bn_apply(int64_t M, int32_t N, const float *X, int64_t ldx, const float *stat, const float *gamma, const float *beta,
+                                  int32_t tanh_out, float *Y, int64_t ldy, void *stream) {
+    OP_NEED(M >= 0 && N >= 1 && stat && gamma && beta && (M == 0 || (X && Y)), "bad argument");
+    HIP_TRY(dn_t_bn_apply(M, N, X, ldx, stat, gamma, beta, tanh_out, Y, ldy, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_bn_bwd_sums(int64_t M, int32_t N, const float *X, int64_t ldx, const float *stat, const float *dOut, int64_t ldd,
+                                     const float *Out, int64_t ldo, int32_t tanh_out, float *sums, float *workspace, void *stream) {
+    OP_NEED(M >= 0 && N >= 1 && stat && sums && workspace && (M == 0 || (X && dOut && (!tanh_out || Out))), "bad argument");
+    HIP_TRY(dn_t_bn_bwd_sums(M, N, X, ldx, stat, dOut, ldd, Out, ldo, tanh_out, sums, workspace, OP_ST));
+    return DAGNET_OK;
+}
+extern "C" int dagnet_op_bn_bwd_apply(int64_t M, int64_t Mtot, int32_t N, const float *X, int64_t ldx, const float *stat, const float *gamma,
+                                      const float *dOut, int64_t ldd, const float *Out, int64_t ldo, int32_t tanh_out, const float *sums,
+                                      float *dX, int64_t ldg, void *stream) {
+    OP_NEED(M >= 0 && Mtot >= M && Mtot >= 1 && N >= 1 && stat && gamma && sums && (M == 0 || (X && dOut && dX && (!tanh_out || Out))), "bad argument");
+    HIP_TRY(dn_t_bn_bwd_apply(M, Mtot, N, X, ldx, stat, gamma, dOut, ldd, Out, ldo, tanh_out, sums, dX, ldg, OP_ST));
+    return DAGNET_OK;
+}
 static int op_plan(const dagnet_plan *p) {
     if (!p) return fail(DAGNET_ERR_INVALID, "null plan");
     int dev = 0;

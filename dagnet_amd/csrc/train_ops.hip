@@ -470,6 +470,78 @@ __global__ __launch_bounds__(256) void bn_finish_stat_kernel(int N, int64_t M, i
     }
 }
 
+// Synchronised BatchNorm (data-parallel training: nn.BatchNorm1d of the reference sees the rows of the WHOLE batch,
+// gat_model.py:21, gcn_model.py:16,18).  A shard's statistics as a mergeable triple per column: mom = [count | mean | M2].
+// Same merge of the splits as bn_finish_stat_kernel.
+__global__ __launch_bounds__(256) void bn_moments_finish_kernel(int N, int64_t M, int splits, int rows_per_split, const float *__restrict__ part,
+                                                                float *__restrict__ mom) {
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (c >= N) return;
+    double n = 0.0, mu = 0.0, q = 0.0;
+    for (int k = lane; k < splits; k += 64) {
+        const int64_t m0 = (int64_t)k * rows_per_split;
+        const double nb = (double)(min(M, m0 + rows_per_split) - m0);
+        if (nb <= 0.0) continue;
+        const double mb = part[((int64_t)k * 2 + 0) * N + c], qb = part[((int64_t)k * 2 + 1) * N + c];
+        const double nn = n + nb, d = mb - mu;
+        mu += d * (nb / nn);
+        q += qb + d * d * (n * nb / nn);
+        n = nn;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double nb = __shfl_xor(n, o), mb = __shfl_xor(mu, o), qb = __shfl_xor(q, o);
+        const double nn = n + nb;
+        if (nn > 0.0) {
+            const double d = mb - mu;
+            mu = (n * mu + nb * mb) / nn;
+            q = q + qb + d * d * (n * nb / nn);
+        }
+        n = nn;
+    }
+    if (lane == 0) {
+        mom[c] = (float)M;
+        mom[N + c] = (float)mu;
+        mom[2 * N + c] = (float)q;
+    }
+}
+// the two-pass fallback's (mean, sum of squared deviations) as the same triple
+__global__ void bn_moments_pack_kernel(int N, int64_t M, const float *__restrict__ mean, const float *__restrict__ var_sum, float *__restrict__ mom) {
+    const int c = (int)gid();
+    if (c >= N) return;
+    mom[c] = (float)M;
+    mom[N + c] = mean[c];
+    mom[2 * N + c] = var_sum[c];
+}
+// Merge of the shards' triples, in shard order and fp64 (every rank holds the same gathered list, so every rank arrives at the
+// same bits), then what bn_stat_kernel does with the merged statistics: stat = [mean | invstd], running statistics with the
+// unbiased variance over ALL rows.  total (nullable): the merged row count, for the backward pass.
+__global__ void bn_merge_kernel(int N, int n_parts, const float *__restrict__ parts, float eps, float momentum, float *__restrict__ stat,
+                                float *__restrict__ run_mean, float *__restrict__ run_var, float *__restrict__ total) {
+    const int c = (int)gid();
+    if (c >= N) return;
+    double n = 0.0, mu = 0.0, q = 0.0;
+    for (int k = 0; k < n_parts; ++k) {
+        const float *pk = parts + (int64_t)k * 3 * N;
+        const double nb = pk[c];
+        if (nb <= 0.0) continue;
+        const double nn = n + nb, d = (double)pk[N + c] - mu;
+        mu += d * (nb / nn);
+        q += (double)pk[2 * N + c] + d * d * (n * nb / nn);
+        n = nn;
+    }
+    const float mean = (float)mu, var_sum = (float)q;
+    const float var = n > 0.0 ? var_sum / (float)n : 0.f;
+    stat[c] = mean;
+    stat[N + c] = 1.0f / sqrtf(var + eps);
+    if (run_mean) {
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * mean;
+        const float unb = n > 1.0 ? var_sum / (float)(n - 1.0) : var;
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * unb;
+    }
+    if (total && c == 0) total[0] = (float)n;
+}
+
 // stage 2: out_q[c] (+)= scale * sum_split part[split][q][c]; one wave per column, lanes stride over the splits
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -529,7 +601,8 @@ __global__ void bn_apply_kernel(int64_t M, int N, const float *__restrict__ X, i
 __global__ void bn_bwd_kernel(int64_t M, int N, const float *__restrict__ X, int64_t ldx, const float *__restrict__ stat,
                               const float *__restrict__ gamma, const float *__restrict__ dOut, int64_t ldd,
                               const float *__restrict__ Out, int64_t ldo, int tanh_out, const float *__restrict__ sums,
-                              float *__restrict__ dX, int64_t ldg) {
+                              float *__restrict__ dX, int64_t ldg, int64_t Mtot) {
+    // Mtot: rows the statistics (and `sums`) were taken over - M, or the rows of ALL shards with synchronised statistics
     const int64_t i = gid();
     if (i >= M * N) return;
     const int64_t m = i / N;
@@ -537,7 +610,7 @@ __global__ void bn_bwd_kernel(int64_t M, int N, const float *__restrict__ X, int
     float g = dOut[m * ldd + c];
     if (tanh_out) { const float o = Out[m * ldo + c]; g *= 1.0f - o * o; }
     const float xhat = (X[m * ldx + c] - stat[c]) * stat[N + c];
-    const float inv_m = 1.0f / (float)M;
+    const float inv_m = 1.0f / (float)Mtot;
     dX[m * ldg + c] = gamma[c] * stat[N + c] * (g - sums[c] * inv_m - xhat * sums[N + c] * inv_m);
 }
 
@@ -1145,7 +1218,56 @@ extern "C" hipError_t dn_t_bn_bwd(int64_t M, int N, const float *X, int64_t ldx,
     if (M == 0 || N == 0) return hipSuccess;
     hipError_t e = col_reduce<2>(M, N, X, ldx, stat, dOut, ldd, Out, ldo, tanh_out, part, 1.0f, sums, sums + N, 0, st, dbeta, dgamma, accumulate);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tops::bn_bwd_kernel, T_GRID(M * N), 0, st, M, N, X, ldx, stat, gamma, dOut, ldd, Out, ldo, tanh_out, sums, dX, ldg);
+    hipLaunchKernelGGL(tops::bn_bwd_kernel, T_GRID(M * N), 0, st, M, N, X, ldx, stat, gamma, dOut, ldd, Out, ldo, tanh_out, sums, dX, ldg, M);
+    return hipGetLastError();
+}
+
+// ---- synchronised BatchNorm in stages (the collectives between them belong to the caller) -------------------------------------
+// stage 1: this shard's mom = [count | mean | M2] per column
+extern "C" hipError_t dn_t_bn_moments(int64_t M, int N, const float *X, int64_t ldx, float *mom, float *tmp, float *part, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    if (M == 0) return hipMemsetAsync(mom, 0, sizeof(float) * 3 * N, st);          // an empty shard: count 0
+    if (((reinterpret_cast<uintptr_t>(X) & 15) == 0) && (ldx & 3) == 0 && ldx >= ((N + 3) & ~3)) {
+        const int splits = col_splits(M);
+        const int rows = (int)((M + splits - 1) / splits);
+        hipLaunchKernelGGL(tops::bn_moments_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, st, M, N, rows, X, ldx, part);
+        hipLaunchKernelGGL(tops::bn_moments_finish_kernel, dim3((N + 3) / 4), dim3(256), 0, st, N, M, splits, rows, part, mom);
+        return hipGetLastError();
+    }
+    hipError_t e = col_reduce<0>(M, N, X, ldx, nullptr, nullptr, 0, nullptr, 0, 0, part, 1.0f / (float)M, tmp, nullptr, 0, st);
+    if (e != hipSuccess) return e;
+    e = col_reduce<1>(M, N, X, ldx, tmp, nullptr, 0, nullptr, 0, 0, part, 1.0f, tmp + N, nullptr, 0, st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tops::bn_moments_pack_kernel, T_GRID(N), 0, st, N, M, tmp, tmp + N, mom);
+    return hipGetLastError();
+}
+// stage 2: merge the gathered triples of all shards -> stat, running statistics, total row count
+extern "C" hipError_t dn_t_bn_merge(int N, int n_parts, const float *parts, float eps, float momentum, float *stat, float *run_mean,
+                                    float *run_var, float *total, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::bn_merge_kernel, T_GRID(N), 0, st, N, n_parts, parts, eps, momentum, stat, run_mean, run_var, total);
+    return hipGetLastError();
+}
+// stage 3: y = (x - mean) invstd gamma + beta (+ tanh) with the merged statistics
+extern "C" hipError_t dn_t_bn_apply(int64_t M, int N, const float *X, int64_t ldx, const float *stat, const float *gamma, const float *beta,
+                                    int tanh_out, float *Y, int64_t ldy, hipStream_t st) {
+    if (M == 0 || N == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::bn_apply_kernel, T_GRID(M * N), 0, st, M, N, X, ldx, stat, gamma, beta, tanh_out, Y, ldy);
+    return hipGetLastError();
+}
+// backward stage 1: this shard's sums = [sum g | sum g xhat] (g = dOut (1 - Out^2) with tanh): its share of dbeta | dgamma
+extern "C" hipError_t dn_t_bn_bwd_sums(int64_t M, int N, const float *X, int64_t ldx, const float *stat, const float *dOut, int64_t ldd,
+                                       const float *Out, int64_t ldo, int tanh_out, float *sums, float *part, hipStream_t st) {
+    if (N == 0) return hipSuccess;
+    if (M == 0) return hipMemsetAsync(sums, 0, sizeof(float) * 2 * N, st);
+    return col_reduce<2>(M, N, X, ldx, stat, dOut, ldd, Out, ldo, tanh_out, part, 1.0f, sums, sums + N, 0, st);
+}
+// backward stage 2: dX from the sums over ALL shards' rows (Mtot of them)
+extern "C" hipError_t dn_t_bn_bwd_apply(int64_t M, int64_t Mtot, int N, const float *X, int64_t ldx, const float *stat, const float *gamma,
+                                        const float *dOut, int64_t ldd, const float *Out, int64_t ldo, int tanh_out, const float *sums,
+                                        float *dX, int64_t ldg, hipStream_t st) {
+    if (M == 0 || N == 0) return hipSuccess;
+    hipLaunchKernelGGL(tops::bn_bwd_kernel, T_GRID(M * N), 0, st, M, N, X, ldx, stat, gamma, dOut, ldd, Out, ldo, tanh_out, sums, dX, ldg, Mtot);
     return hipGetLastError();
 }
 

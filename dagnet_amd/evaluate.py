@@ -28,13 +28,13 @@ def evaluate_helper(error, seq_start_end):
 
 def rollout_best_of_k(model, args, batch, num_samples, seed=None, batch_index=0):
     """One batch of ``evaluate``: -> dict(ade_sum, fde_sum (fp64 device scalars), samples_rel [K,T,N,2], n_agents).
-    ``seed``: the teacher-forced pass and the rollout draw from Philox streams of their own (2 (seed + batch_index) and
-    2 (seed + batch_index) + 1), so the rollout noise is independent of the noise that produced h."""
+    ``seed``: the teacher-forced pass and the rollout draw from Philox streams of their own (loop.sub_seed: a hash of seed, batch
+    index, phase and rank), so the rollout noise is independent of the noise that produced h and differs from rank to rank."""
     obs_traj, pred_traj_gt, obs_traj_rel, pred_traj_rel_gt, obs_goals, pred_goals_gt = batch[:6]
     seq_start_end = batch[-1]                     # 7-tuple (basketball loader) or 9-tuple (SDD loader): last field
     sp = scene_ptr_from_sse(seq_start_end, obs_traj.shape[1])
-    seed_f = None if seed is None else 2 * (int(seed) + int(batch_index))
-    seed_s = None if seed is None else seed_f + 1
+    from .loop import sub_seed
+    seed_f, seed_s = sub_seed(seed, batch_index, 0), sub_seed(seed, batch_index, 1)
     if isinstance(model, DAGNet):
         adj = _obs_adjacency(args, seq_start_end, obs_traj, pred_traj_gt)
         goals = obs_goals.to(torch.int32)

@@ -11,6 +11,8 @@ batch).
 from __future__ import annotations
 
 import numpy as np
+import os
+
 import torch
 
 from . import _ops, training
@@ -41,11 +43,37 @@ def _split(data, kind):
     return obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, data[-1]
 
 
-def sub_seed(seed, batch_index, phase):
-    """Philox seed of one call site: the counter of csrc/rng.h is (row, t, j, stream) only, so the teacher-forced pass
-    (phase 0) and the rollout (phase 1) of one batch, and the batches of one epoch, get seeds of their own -
-    2 (seed + batch_index) + phase - instead of drawing the same numbers at the same (row, t).  None stays None."""
-    return None if seed is None else 2 * (int(seed) + int(batch_index)) + int(phase)
+_M64 = (1 << 64) - 1
+
+
+def _mix64(x):
+    """splitmix64 finaliser: a bijection of 64-bit integers with good avalanche."""
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & _M64
+    return x ^ (x >> 31)
+
+
+def sub_seed(seed, batch_index, phase, rank=None):
+    """Philox seed of one call site.  The counter of csrc/rng.h is (local row, t, j, stream) only, so everything else that
+    must not share noise goes into the key: the teacher-forced pass (phase 0) and the rollout (phase 1) of one batch, the
+    batches of one epoch, the epoch functions (``epoch_seed``) and - data parallel - the RANK, whose shard numbers its rows
+    from 0 like every other rank's.  A hash of the tuple, not a sum: (seed, batch b + 1) and (seed + 1, batch b) differ
+    (ADVICE r2).  None stays None; the result fits 63 bits."""
+    if seed is None:
+        return None
+    if rank is None:
+        rank = torch.distributed.get_rank() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 0
+    h = _mix64(int(seed) & _M64)
+    for v in (batch_index, phase, rank):
+        h = _mix64(h ^ (int(v) & _M64))
+    return h >> 1
+
+
+def epoch_seed(seed, epoch, what):
+    """Seed of one epoch function (what: 0 validate, 1 test, 2 evaluate(test), 3 evaluate(valid)) - hashed, so that no two of them
+    and no two epochs meet whatever the batch count."""
+    return None if seed is None else _mix64(_mix64(int(seed) & _M64) ^ ((int(epoch) << 8) | int(what))) >> 1
 
 
 def _dist_on():
@@ -137,24 +165,37 @@ def _full_adjacency(args, sse, obs, gt):
     return compute_adjs_knnsim(args, sse, obs, gt, compact=True)
 
 
-def train(args, epch, train_loader, model, warmup, optimizer):
+def train(args, epch, train_loader, model, warmup, optimizer, sync_batchnorm=None):
     """train_bsk.py:251-312: one epoch of optimizer steps.  DAG-Net trains on the full obs + pred sequence, A-VRNN and
     VRNN on the observed steps only (models/avrnn/train_bsk.py:256, models/baseline/train_bsk.py:218).
     ``optimizer`` is an ``_ops.ClipAdam`` (clip_grad_norm_(args.clip) + Adam in one).  -> mean losses per scene.
     Data parallel (torch.distributed initialised, the loader handing every rank its share of each batch): a rank scales
     its KLD / NLL (means over rows) by its share of the batch's rows so that the all-reduced gradients are the
     single-process ones; a rank whose share is empty still joins the gradient all-reduce and steps the optimizer; the
-    epoch's loss sums are all-reduced once."""
+    epoch's loss sums are all-reduced once.
+    ``sync_batchnorm`` (default: the environment variable DAGNET_SYNC_BN): train-mode BatchNorm statistics over the rows of ALL
+    ranks, as the reference's single-process BatchNorm sees them (_ops.SyncBnFn: one all-gather + one all-reduce of a few hundred
+    bytes per BatchNorm call); off, every rank normalises with its own shard's statistics.  With it a rank
+    whose share of a batch is EMPTY cannot skip the forward pass's collectives: use batches of at least one scene per rank."""
+    from . import _ops
     kind = _kind(model)
     dev = next(model.parameters()).device
     acc = torch.zeros(4, dtype=torch.float64, device=dev)
     w = float(warmup[epch - 1])
+    if sync_batchnorm is None:
+        sync_batchnorm = os.environ.get("DAGNET_SYNC_BN", "0") not in ("", "0")
+    sync = bool(sync_batchnorm) and _dist_on() and kind != "vrnn"
     for data in train_loader:
         obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = _split([t.to(dev) for t in data], kind)
         frac = _row_fraction(train_loader, obs.shape[1], dev)
         if obs.shape[1] == 0:
+            if sync:
+                raise RuntimeError("synchronised BatchNorm needs at least one scene per rank in every batch (this rank's share is empty)")
             training.empty_step(model, optimizer)
             continue
+        prev_bn = _ops.set_sync_batchnorm("dist") if sync else None
+        if sync:
+            _ops.BN_SYNC.rows_all = int(round(obs.shape[1] / frac))
         if kind == "dagnet":
             assert len(obs) + len(gt) == args.obs_len + args.pred_len
             adj = _full_adjacency(args, sse, obs, gt)
@@ -165,6 +206,9 @@ def train(args, epch, train_loader, model, warmup, optimizer):
             r = training.train_step(model, optimizer, (obs_rel, _full_adjacency(args, sse, obs, gt), sse), kld_weight=w, row_fraction=frac)
         else:
             r = training.train_step(model, optimizer, (obs_rel,), kld_weight=w, row_fraction=frac)
+        if sync:
+            _ops.set_sync_batchnorm(*prev_bn)
+            _ops.BN_SYNC.rows_all = None
         acc[0] += r["loss"][0].double(); acc[1] += frac * r["kld"][0].double(); acc[2] += frac * r["nll"][0].double(); acc[3] += r["ce"][0].double()
     if _dist_on():
         torch.distributed.all_reduce(acc)
@@ -286,18 +330,17 @@ def fit(args, model, train_loader, valid_loader, test_loader, start_epoch=0, bes
     ctx = FitContext(args, model, optimizer, sched, hist)
     for epoch in range(start_epoch + 1, args.num_epochs + 1):
         ctx.epoch = epoch
-        e_seed = None if seed is None else seed + 7919 * epoch          # fresh evaluation noise every epoch
         hist["train"].append(train(args, epoch, train_loader, model, warmup, optimizer))
-        ade, _ = validate(args, epoch, valid_loader, model, warmup, sched, seed=e_seed)
+        ade, _ = validate(args, epoch, valid_loader, model, warmup, sched, seed=epoch_seed(seed, epoch, 0))      # fresh noise every epoch
         hist["val"].append(validate.last)
-        hist["test"].append(test(args, epoch, test_loader, model, warmup, seed=None if e_seed is None else e_seed + 1009))
+        hist["test"].append(test(args, epoch, test_loader, model, warmup, seed=epoch_seed(seed, epoch, 1)))
         if 0 <= ade < hist["best_ade"]:
             hist["best_ade"] = ade
             if on_best is not None:
                 on_best(epoch, ade, ctx)
         if getattr(args, "eval_every", 0) and epoch % args.eval_every == 0:
-            a, f = evaluate(args, model, test_loader, args.num_samples, seed=None if e_seed is None else e_seed + 2003)
-            av, fv = evaluate(args, model, valid_loader, args.num_samples, seed=None if e_seed is None else e_seed + 3001)
+            a, f = evaluate(args, model, test_loader, args.num_samples, seed=epoch_seed(seed, epoch, 2))
+            av, fv = evaluate(args, model, valid_loader, args.num_samples, seed=epoch_seed(seed, epoch, 3))
             hist["ade_list_test"].append((a, epoch)); hist["fde_list_test"].append((f, epoch))
             hist["ade_list_val"].append((av, epoch)); hist["fde_list_val"].append((fv, epoch))
         if on_epoch is not None:

@@ -284,11 +284,16 @@ def allreduce_gradients(params, world_size=None):
     if arena is not None:                      # attach_grad_arena: the gradients already are one flat buffer
         dist.all_reduce(arena)
         return
-    grads = [p.grad for p in params if p.grad is not None]
-    flat = torch.cat([g.reshape(-1) for g in grads])
+    # every parameter takes part, a missing gradient as zeros: the ranks' flat buffers must have the same length whatever
+    # each rank's graph touched (an empty shard's empty_step materialises zeros for all of them)
+    params = [p for p in params if p.requires_grad]
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
     dist.all_reduce(flat)
     off = 0
-    for g in grads:
-        n = g.numel()
-        g.copy_(flat[off:off + n].view_as(g))
+    for p in params:
+        n = p.numel()
+        if p.grad is None:
+            p.grad = flat[off:off + n].view_as(p).clone()
+        else:
+            p.grad.copy_(flat[off:off + n].view_as(p))
         off += n

@@ -333,6 +333,28 @@ int dagnet_op_bn_fwd(int64_t M, int32_t N, const float *X, int64_t ldx, const fl
 int dagnet_op_bn_bwd(int64_t M, int32_t N, const float *X, int64_t ldx, const float *stat, const float *gamma, const float *dOut,
                      int64_t ldd, const float *Out, int64_t ldo, int32_t tanh_out, float *dX, int64_t ldg, float *dgamma,
                      float *dbeta, int32_t accumulate, float *sums, float *workspace, void *stream);
+/* Replaces: the same BatchNorm when the batch is sharded over ranks (data-parallel training): the reference's
+ * nn.BatchNorm1d takes its statistics over ALL rows of the batch (gat_model.py:21, gcn_model.py:16,18), so the shards exchange
+ * mergeable moments.  The stages between which the caller runs its collectives:
+ *   dagnet_op_bn_moments  -> mom [3N] = count | mean | sum of squared deviations of this shard's M rows (M = 0: zeros);
+ *   (all-gather mom over the ranks: parts [n_parts][3N], rank order)
+ *   dagnet_op_bn_merge    -> stat [2N] = mean | invstd over all rows (fp64 merge in rank order: every rank gets the same bits),
+ *                            running statistics updated as nn.BatchNorm1d does with the whole batch, total[0] = all rows;
+ *   dagnet_op_bn_apply    -> Y = (X - mean) invstd gamma + beta (+ tanh);
+ *   dagnet_op_bn_bwd_sums -> sums [2N] = sum g | sum g xhat over this shard (= its share of dbeta | dgamma);
+ *   (all-reduce(SUM) sums over the ranks)
+ *   dagnet_op_bn_bwd_apply-> dX from the all-reduced sums and Mtot = all rows.
+ * tmp [2N] scratch; workspace: dagnet_op_col_workspace(M, N) floats. */
+int dagnet_op_bn_moments(int64_t M, int32_t N, const float *X, int64_t ldx, float *mom, float *tmp, float *workspace, void *stream);
+int dagnet_op_bn_merge(int32_t N, int32_t n_parts, const float *parts, float eps, float momentum, float *stat, float *run_mean,
+                       float *run_var, float *total, void *stream);
+int dagnet_op_bn_apply(int64_t M, int32_t N, const float *X, int64_t ldx, const float *stat, const float *gamma, const float *beta,
+                       int32_t tanh_out, float *Y, int64_t ldy, void *stream);
+int dagnet_op_bn_bwd_sums(int64_t M, int32_t N, const float *X, int64_t ldx, const float *stat, const float *dOut, int64_t ldd,
+                          const float *Out, int64_t ldo, int32_t tanh_out, float *sums, float *workspace, void *stream);
+int dagnet_op_bn_bwd_apply(int64_t M, int64_t Mtot, int32_t N, const float *X, int64_t ldx, const float *stat, const float *gamma,
+                           const float *dOut, int64_t ldd, const float *Out, int64_t ldo, int32_t tanh_out, const float *sums, float *dX,
+                           int64_t ldg, void *stream);
 /* Replaces: GraphAttentionLayer.forward (gat_layers.py:25-40) after Wh = x W, per scene of the plan, for H heads of width F
  * stacked along the columns of Wh; a [H][2F].  adj: compact block-diagonal (adj_ld 0) or dense [N,N] (adj_ld N).
  * Backward: dWh and da_part [S][H*2F], every scene's contribution to the gradient of a (sum its columns with

@@ -206,3 +206,24 @@ def test_sdd_trajectory_dataset_reads_the_reference_file_layout(tmp_path):
                                 goals_window=3)
     assert np.array_equal(ds.obs_traj.numpy(), SDD_GOLD["skip1_obs_traj"])
     assert np.array_equal(ds.pred_goals.numpy(), SDD_GOLD["skip1_pred_goals"])
+
+
+def test_sub_seeds_do_not_collide():
+    """seeds of call sites were sums (2 (seed + batch) + phase; epoch functions at +1009 / +2003 / +3001), so
+    (seed, batch b + 1) met (seed + 1, batch b) and validate's batch 1009 met test's batch 0; and every rank drew the same
+    noise for its row i.  Now a hash of (seed, batch, phase, rank) / (seed, epoch, function)."""
+    from dagnet_amd import loop
+    seen = {}
+    for seed in range(4):
+        for b in range(40):
+            for phase in (0, 1):
+                for rank in range(3):
+                    v = loop.sub_seed(seed, b, phase, rank)
+                    assert 0 <= v < (1 << 63)
+                    assert v not in seen, (seed, b, phase, rank, seen.get(v))
+                    seen[v] = (seed, b, phase, rank)
+    assert loop.sub_seed(None, 1, 0) is None and loop.sub_seed(5, 1, 0, 0) == loop.sub_seed(5, 1, 0, 0)
+    ep = {loop.epoch_seed(s, e, w) for s in range(3) for e in range(1, 50) for w in range(4)}
+    assert len(ep) == 3 * 49 * 4 and loop.epoch_seed(None, 1, 0) is None
+    # an epoch function's batches never meet another function's: (epoch_seed(.., 0), batch 1009) vs (epoch_seed(.., 1), batch 0)
+    assert loop.sub_seed(loop.epoch_seed(7, 3, 0), 1009, 0, 0) != loop.sub_seed(loop.epoch_seed(7, 3, 1), 0, 0, 0)

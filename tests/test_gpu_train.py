@@ -302,3 +302,73 @@ def test_second_forward_before_backward_is_refused():
         p.grad = None
     (kld2 + nll2).backward()                        # the graph of the LAST forward is intact
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in model.parameters())
+
+
+BN_CASES = [n for n in cases.list_train_cases() if "vrnn" not in n or "avrnn" in n]      # the models with a BatchNorm (graph models)
+
+
+@pytest.mark.parametrize("name", BN_CASES)
+def test_sync_batchnorm_virtual_shards_match_the_whole_batch_golden(name):
+    """Synchronised BatchNorm for data-parallel training: the batch is cut into two row shards that go through
+    the staged kernels - moments per shard -> merge -> apply; backward sums per shard -> add -> apply (what the ranks do around
+    their all-gather / all-reduce, _ops.SyncBnFn) - and the step must equal the reference's WHOLE-batch step: losses, every
+    gradient, total norm, Adam step, running statistics, at the tolerances of the unsharded test."""
+    from dagnet_amd import _ops
+    meta, gold = cases.load_golden(name)
+    _, model, _ = cases.build_model(meta)
+    model = model.to(DEV)
+    sizes = meta["sizes"]
+    cut = int(sum(sizes[:max(1, len(sizes) // 2)]))
+    prev = _ops.set_sync_batchnorm("virtual", [0, cut, int(sum(sizes))])
+    try:
+        out = hip_train_step(meta, model)
+    finally:
+        _ops.set_sync_batchnorm(*prev)
+    check_step(out, gold, meta["lr"], meta["clip"])
+
+
+def test_per_shard_batchnorm_deviates_from_the_whole_batch_step():
+    """What the default (per-rank BatchNorm statistics) costs under data parallelism: the same batch as two scene shards, each a
+    forward / backward of its own with row_fraction weighting, gradients summed as the all-reduce would - against the reference's
+    whole-batch gradients.  The deviation is real (far above the parity tolerance) and is recorded in DESIGN.md section 6."""
+    from dagnet_amd import _ops
+    from dagnet_amd.adjacency_matrix import compute_adjs_distsim
+    from dagnet_amd.sharding import shard_batch
+    from dagnet_amd.utils import to_goals_one_hot
+    name = "train_dagnet_bsk_gat_n5"
+    meta, gold = cases.load_golden(name)
+    args, model, _ = cases.build_model(meta)
+    model = model.to(DEV).train()
+    batch, eps = cases.build_train_inputs(meta)
+    sizes = meta["sizes"]
+    N = int(sum(sizes))
+    total = {k: torch.zeros_like(p) for k, p in model.named_parameters()}
+    bn_before = {k: v.clone() for k, v in model.state_dict().items() if "running" in k}
+    for r in range(2):
+        (obs, gt, obs_rel, gt_rel, og, pg, sse), local = shard_batch(batch, sizes, 2, r)
+        lo = int(sum(sizes[:0 if r == 0 else len(sizes) - len(local)]))
+        n_loc = int(local.sum())
+        e = eps[:, lo:lo + n_loc].to(DEV)
+        obs, gt, obs_rel, gt_rel, og, pg = [t.to(DEV) for t in (obs, gt, obs_rel, gt_rel, og, pg)]
+        traj, rel = torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0)
+        adj = compute_adjs_distsim(args, sse, obs, gt)
+        g_ohe = to_goals_one_hot(torch.cat((og, pg), 0), args.g_dim)
+        for p in model.parameters():
+            p.grad = None
+        kld, nll, ce, _ = model(traj, rel, g_ohe, sse, adj, eps=e)
+        loss = (n_loc / N) * (meta["kld_weight"] * kld + nll) + meta["ce_weight"] * ce
+        loss.backward()
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                total[k] += p.grad
+        for k, v in bn_before.items():                      # each "rank" starts from the same running statistics
+            model.state_dict()[k].copy_(v)
+    worst, worst_key = 0.0, None
+    for key, want in gold.items():
+        if key.startswith("grad/"):
+            got = total[key[5:]].cpu().numpy()
+            dev = float(np.abs(got - want).max() / (np.abs(want).max() + 1e-12))
+            if np.abs(want).max() > 1e-3 * float(gold["total_norm"]) and dev > worst:
+                worst, worst_key = dev, key[5:]
+    print(f"\nper-shard BatchNorm, 2 shards of {name}: worst gradient deviation {worst:.3f} of the tensor's max |g| ({worst_key})")
+    assert worst > 10 * cases.GRAD_RTOL, "per-shard statistics should differ visibly from whole-batch statistics on 15 rows"

@@ -414,6 +414,9 @@ template <int KT, int NT, bool BF = false, class PF = NoProf>
 __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WBuf &wp, const V2Gat &Gw, unsigned amask,
                                     float slope, float *xch, const float *gf, int lane, WBlk pre, int next_off, PF ph = PF()) {
     const int lh = lane >> 5, lc = lane & 31;
+    // the mask addends are rebuilt per call (16 selects): with the same mask in both graphs of a step the compiler otherwise
+    // keeps the 16 values of the goal graph's call alive - in scratch memory - until the hidden graph's
+    asm volatile("" : "+v"(amask));
     // Wh for all heads, transposed: lane = head feature, register = tile row
     T16 whT[1];
     zero(whT);

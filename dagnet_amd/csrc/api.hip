@@ -102,6 +102,7 @@ struct dagnet_model {
     V2Weights w2[2];            // absolute offsets into d_wp (read by model 3 only: wide goal head)
     V2Weights *d_w2[2] = {nullptr, nullptr};  // device copies of w2
     int v2_base[2] = {0, 0};    // start of the v2 regions in d_wp: the v2 kernels use compile-time offsets relative to them
+    bool split_ok = true;       // every weight fits fp16's range: the split region is usable
     // wide goal head (wide_head.hip) + register-resident kernel model 3 for the rest of the step
     bool wide = false;
     WideWeights ww;
@@ -211,22 +212,17 @@ struct Packer {
                         }
         return off;
     }
-    // The same blocks for the bf16 matrix pipe (params_v2.h, v2_common.h mm<..., BF = true>): every weight as three bf16 terms by
-    // truncation (8 + 8 + 8 significant bits: hi + mid + lo is the weight exactly); a half block (output tile nt, input tile kt,
-    // k-half p) = [term][lane 64][8 bf16], slot s of lane (n, h) = W[nt*32+n][kt*32 + 8*(2p + s/4) + 4h + s%4]; 768 dwords.
+    // The same blocks for the 16-bit matrix pipe (params_v2.h, v2_common.h mm<..., BF = true>): every weight as two fp16 terms,
+    // rounded to nearest (hi = fp16(w), lo = fp16(w - hi): 22 significant bits); a half block (output tile nt, input tile kt,
+    // k-half p) = [term][lane 64][8 fp16], slot s of lane (n, h) = W[nt*32+n][kt*32 + 8*(2p + s/4) + 4h + s%4]; 512 dwords.
     // kt_major: half blocks ordered [kt][p][nt] (dense layers: half an input tile is split once for all output tiles),
     // else [nt][kt][p] (one output tile per product).
-    bool bf = false;            // v2 region being packed: chain_v2() emits split-bf16 blocks
-    int chain3(const WFn &W, int N, int K, bool kt_major) {
+    bool bf = false;            // v2 region being packed: chain_v2() emits split blocks
+    int chain_split(const WFn &W, int N, int K, bool kt_major) {
         const int nt = (N + 31) / 32, kt = (K + 31) / 32;
         const int off = align();
-        buf.resize(off + (size_t)nt * kt * V2_BLOCK_BF3, 0.f);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(buf.data() + off);
-        auto trunc_bf16 = [](float v) -> uint32_t {
-            uint32_t u;
-            memcpy(&u, &v, 4);
-            return u & 0xffff0000u;
-        };
+        buf.resize(off + (size_t)nt * kt * V2_BLOCK_SPLIT, 0.f);
+        uint16_t *dst = reinterpret_cast<uint16_t *>(buf.data() + off);
         for (int a = 0; a < nt; ++a)
             for (int b = 0; b < kt; ++b)
                 for (int p = 0; p < 2; ++p) {
@@ -235,20 +231,21 @@ struct Packer {
                         for (int sl = 0; sl < 8; ++sl) {
                             const int n = a * 32 + (l & 31), k = b * 32 + 8 * (2 * p + sl / 4) + 4 * (l >> 5) + sl % 4;
                             float v = (n < N && k < K) ? W(n, k) : 0.f;
-                            for (int t = 0; t < 3; ++t) {
-                                const uint32_t hi = trunc_bf16(v);
-                                float hf;
-                                memcpy(&hf, &hi, 4);
-                                v -= hf;                                   // exact: the top 8 significant bits removed
-                                uint32_t &word = dst[half * V2_HALF_BF3 + ((size_t)t * 64 + l) * 4 + sl / 2];
-                                word = (sl & 1) ? ((word & 0x0000ffffu) | hi) : ((word & 0xffff0000u) | (hi >> 16));
+                            for (int t = 0; t < 2; ++t) {
+                                const _Float16 hv = (_Float16)v;          // round to nearest even; beyond 65504: +-inf (refused below)
+                                uint16_t bits;
+                                memcpy(&bits, &hv, 2);
+                                if ((bits & 0x7c00u) == 0x7c00u) split_overflow = true;
+                                v -= (float)hv;
+                                dst[(half * V2_HALF_SPLIT + ((size_t)t * 64 + l) * 4) * 2 + sl] = bits;
                             }
                         }
                 }
         return off;
     }
+    bool split_overflow = false;      // a weight beyond the fp16 range (or not finite): the model keeps the fp32 kernels
     // the v2 regions' dense segments: fp32 chain order or split-bf16 blocks, as the region being packed says
-    int chain_v2(const WFn &W, int N, int K, bool kt_major) { return bf ? chain3(W, N, K, kt_major) : chain(W, N, K); }
+    int chain_v2(const WFn &W, int N, int K, bool kt_major) { return bf ? chain_split(W, N, K, kt_major) : chain(W, N, K); }
     // plain row-major [N][ld] (ld >= K, zero padded): operands of the batched GEMMs (gemm_f32.hip)
     int rowmajor(const WFn &W, int N, int K, int ld) {
         const int off = align();
@@ -940,6 +937,7 @@ extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor
             pk.bf = bf != 0;
             v2_pack(pk, c, m->w2[bf], m->wide);
             pk.bf = false;
+            if (bf) m->split_ok = !pk.split_overflow;
             if (pk.missing.empty() && !m->wide) {      // (model 3 reads the table: its one-hot tables have g_dim rows)
                 const int code = dag && Dd > 32 ? 4 : c.model;
                 const std::string bad = v2_check_layout(m->w2[bf], m->v2_base[bf], pk.align() - m->v2_base[bf], code, c.n_layers, c.z_dim,
@@ -1321,7 +1319,7 @@ static DnNanDst nan_dst(void *p, int64_t plane_stride, int64_t planes, int cols)
     return DnNanDst{static_cast<uint32_t *>(p), plane_stride, planes, cols};
 }
 
-// The rollout kernels' dense products: split bf16 (three bf16 terms per fp32 value on the bf16 matrix pipe) unless switched off -
+// The rollout kernels' dense products: split (two fp16 terms per fp32 value on the 16-bit matrix pipe, params_v2.h) unless switched off -
 // DAGNET_NO_BF16X3 in the environment or bit 3 of dagnet_op_set_fused, the switch of the wide GEMM's split products.
 static int fused_mask();
 static int rollout_bf3() { return (fused_mask() >> 3) & 1; }
@@ -1331,7 +1329,7 @@ static int sample_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, c
                        float *d_out, int32_t *d_out_goals, void *stream) {
     if (!m || !p) return fail(DAGNET_ERR_INVALID, "null argument");
     if (m->v2 && p->n_tiles2 > 0 && !getenv("DAGNET_FORCE_GENERIC")) {
-        const int bf = rollout_bf3();
+        const int bf = rollout_bf3() && m->split_ok;
         V2Run r;
         memset(&r, 0, sizeof(r));
         r.wp = m->d_wp + m->v2_base[bf];      // rollout_v2: compile-time offsets relative to the v2 region
@@ -1354,7 +1352,7 @@ static int sample_impl(const dagnet_model *m, const dagnet_plan *p, int32_t T, c
         // register-resident kernel (model 3) with the drawn goals; state lives in the plan's workspace
         hipStream_t st = static_cast<hipStream_t>(stream);
         const DnDims &D = m->dims;
-        const int bf = rollout_bf3();
+        const int bf = rollout_bf3() && m->split_ok;
         HIP_TRY(dn_wide_init_state(p->N, p->K, D.L, D.R, D.G, d_h0, d_x0, d_g0, p->wb.h, p->wb.pos, p->wb.goal, st));
         WideStep ws;
         memset(&ws, 0, sizeof(ws));

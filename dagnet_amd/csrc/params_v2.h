@@ -58,15 +58,21 @@ struct V2Weights {
 // ---------------------------------------------------------------------------------------------
 #define V2_GT 3     // goal tiles (g_dim <= 96)
 
-// Split-bf16 packing (bf = 1; v2_common.h mm<..., BF = true>, api.hip Packer::chain3): every fp32 weight is three bf16 terms
-// (8 + 8 + 8 significant bits by truncation: hi + mid + lo IS the weight), and a 32 x 32 block is
-//     two half blocks (k-half p = 0, 1) of [term 0..2][lane 64] 8 x bf16 = W_term[32*nt + n][32*kt + 8*(2p + s/4) + 4*h + s%4], s = 0..7
-// - the operand of v_mfma_f32_32x32x16_bf16 whose 8 k-slots of lane half h are registers 8p .. 8p+7 of an input tile -
-// i.e. 2 x 768 dwords where the fp32 block has 1024.  Dense layers are streamed [kt][p][nt] (half an input tile is split once
-// and feeds all output tiles); GRU gates and the graph layers' per-tile products are one output tile per call: [nt][kt][p].
+// Split packing (bf = 1; v2_common.h mm<..., BF = true>, api.hip Packer::chain_split): the dense products of the rollout kernels
+// run on the 16-bit matrix pipe with every fp32 value as TWO fp16 terms (11 + 11 significant bits, round to nearest: hi = fp16(v),
+// lo = fp16(v - hi)) and three products (hi hi, hi lo, lo hi; the dropped lo lo is below 2^-22 of the product) accumulated in
+// fp32 - measured error of an 8-layer chain against fp64: 2.4e-6 max / 1.4e-7 mean, the fp32 MFMA's 2.2e-6 / 1.1e-7
+// (tools/ubench/split_bf16.hip, profiles/r03_split_ubench.txt; three bf16 terms / six products, the first form of this round:
+// 1.1e-6, at 1.65 x the time).  fp16 keeps fp32's range only up to 65504: a layer INPUT beyond that overflows (activations of
+// these models are O(1) .. O(100)); values below 6e-5 are fp16 subnormals, kept by the matrix pipe (absolute error 3e-8).
+// A 32 x 32 weight block is two half blocks (k-half p = 0, 1) of
+//     [term hi, lo][lane 64] 8 x fp16 = W_term[32*nt + n][32*kt + 8*(2p + s/4) + 4*h + s%4], s = 0..7
+// - the operand of v_mfma_f32_32x32x16_f16 whose 8 k-slots of lane half h are registers 8p .. 8p+7 of an input tile - i.e. 2 x 512
+// dwords, the size of the fp32 block.  Dense layers are streamed [kt][p][nt] (half an input tile is split once and feeds all
+// output tiles); the graph layers' per-tile products are one output tile per call: [nt][kt][p].
 #define V2_BLOCK_F32 1024
-#define V2_BLOCK_BF3 1536
-#define V2_HALF_BF3 768
+#define V2_BLOCK_SPLIT 1024
+#define V2_HALF_SPLIT 512
 
 struct V2Layout {
     V2Weights off;      // relative float offsets
@@ -82,7 +88,7 @@ struct V2Layout {
 constexpr V2Layout v2_layout(int model, int nl, int zd, int gm, int bf = 0) {
     V2Layout L{};
     int32_t cur = 0;
-    const int BS = bf ? V2_BLOCK_BF3 : V2_BLOCK_F32;
+    const int BS = bf ? V2_BLOCK_SPLIT : V2_BLOCK_F32;
     const bool dag = model >= 2, graph = model != 0, head = model == 2 || model == 4;
     const int DT = (model == 3 || model == 4) ? 2 : 1, GT = V2_GT, GP = V2_GT * 32;
     const int zt2 = (2 * zd + 31) / 32;

@@ -83,32 +83,32 @@ __device__ __forceinline__ void zero(T16 (&x)[N]) {
 }
 
 // Weights in flight.  fp32 (BF = false): one (n-tile, k-tile) block = 4 x float4 per lane = the A (or B) operands of 16
-// v_mfma_f32_32x32x2_f32, in v[0..3].  Split bf16 (BF = true, params_v2.h): the unit is a HALF block - one output tile x one
-// k-half (16 input features) x three bf16 terms = 3 x 16 bytes per lane, the weight operands of 6 v_mfma_f32_32x32x16_bf16 -
-// and V2_BF_DEPTH of them are in flight: v[3*d + term] = half block d of the consumer's stream.
+// v_mfma_f32_32x32x2_f32, in v[0..3].  Split fp16 (BF = true, params_v2.h): the unit is a HALF block - one output tile x one
+// k-half (16 input features) x two fp16 terms = 2 x 16 bytes per lane, the weight operands of 3 v_mfma_f32_32x32x16_f16 -
+// and V2_BF_DEPTH of them are in flight: v[2*d + term] = half block d of the consumer's stream.
 #ifndef V2_BF_DEPTH
-#define V2_BF_DEPTH 2
+#define V2_BF_DEPTH 3
 #endif
-#ifdef DN_V2_NOFENCE      // experiment: leave the order of splits, loads and MFMAs of the split-bf16 products to the compiler
+#ifdef DN_V2_NOFENCE      // experiment: leave the order of splits, loads and MFMAs of the split products to the compiler
 #define V2_FENCE()
 #else
 #define V2_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
 struct WBlk {
-    float4 v[3 * V2_BF_DEPTH > 4 ? 3 * V2_BF_DEPTH : 4];
+    float4 v[2 * V2_BF_DEPTH > 4 ? 2 * V2_BF_DEPTH : 4];
 };
-// the three quads of one half block into slot d
+// the two quads of one half block into slot d
 __device__ __forceinline__ void wload_half(WBlk &b, int d, const WBuf &wp, int off, int lane) {
     asm volatile("" : "+s"(off));     // keep the scalar offset out of loop-invariant hoisting (SGPR spills)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) b.v[3 * d + j] = wp.ld4(lane * 16 + j * 1024, off);
+    for (int j = 0; j < 2; ++j) b.v[2 * d + j] = wp.ld4(lane * 16 + j * 1024, off);
 }
 template <bool BF = false>
 __device__ __forceinline__ WBlk wload(const WBuf &wp, int off, int lane) {
     WBlk b;
     if constexpr (BF) {
 #pragma unroll
-        for (int d = 0; d < V2_BF_DEPTH; ++d) wload_half(b, d, wp, off + d * V2_HALF_BF3, lane);
+        for (int d = 0; d < V2_BF_DEPTH; ++d) wload_half(b, d, wp, off + d * V2_HALF_SPLIT, lane);
     } else {
         asm volatile("" : "+s"(off));
 #pragma unroll
@@ -117,39 +117,36 @@ __device__ __forceinline__ WBlk wload(const WBuf &wp, int off, int lane) {
     return b;
 }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-#define MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
-__device__ __forceinline__ bf16x8 as_bf8(float4 v) { return __builtin_bit_cast(bf16x8, v); }
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define MFMA_H(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+__device__ __forceinline__ f16x8 as_h8(float4 v) { return __builtin_bit_cast(f16x8, v); }
 
-// Registers 8p .. 8p+7 of an S- or T-layout tile as three bf16 terms, truncated (v_and / v_sub / v_perm: full-rate
-// instructions; 8 + 8 + 8 significant bits, so hi + mid + lo IS the value): t[term] = the 8 k-slots of one
-// v_mfma_f32_32x32x16_bf16 operand (slot s = register 8p + s: the order the weights are packed in, params_v2.h).
-struct XSplit {
-    float4 t[3];
-};
+// Registers 8p .. 8p+7 of an S- or T-layout tile as two fp16 terms, rounded to nearest: hi = fp16(v), lo = fp16(v - hi) (the
+// difference is exact in fp32) - per pair of values v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32.
+// t[term] = the 8 k-slots of one v_mfma_f32_32x32x16_f16 operand (slot s = register 8p + s: the order the weights are packed in).
 // The values are read through an opaque copy: left alone, the compiler recognises the split of a tile that several products
-// read (h, phi_z, the GRU's inputs) as a common subexpression and keeps all 24 registers per tile alive from the first use to
-// the last - the register file does not have them (it spilled ~100 registers per lane); a split is 38 instructions per half tile.
-__device__ __forceinline__ void split3(const T16 &x, int p, XSplit &s) {
-    unsigned pk[3][4];
+// read (h, phi_z, the GRU's inputs) as a common subexpression and keeps its registers alive from the first use to the last -
+// the register file does not have them (the first version spilled ~100 registers per lane).
+struct XSplit {
+    float4 t[2];
+};
+__device__ __forceinline__ void split2(const T16 &x, int p, XSplit &s) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    unsigned pk[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float v0 = x[8 * p + 2 * j], v1 = x[8 * p + 2 * j + 1];
         asm volatile("" : "+v"(v0), "+v"(v1));
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const unsigned u0 = __float_as_uint(v0), u1 = __float_as_uint(v1);
-            pk[t][j] = __builtin_amdgcn_perm(u1, u0, 0x07060302u);      // {hi16(v1), hi16(v0)}
-            if (t < 2) {       // one v_pk_add_f32 for the pair (tools/ubench/split_forms.hip: 508 against 556 clocks per tile)
-                typedef float f2 __attribute__((ext_vector_type(2)));
-                const f2 v = f2{v0, v1} - f2{__uint_as_float(u0 & 0xffff0000u), __uint_as_float(u1 & 0xffff0000u)};
-                v0 = v.x;
-                v1 = v.y;
-            }
-        }
+        const f2 v = {v0, v1};
+        const h2 hi = __builtin_convertvector(v, h2);
+        const f2 r = v - __builtin_convertvector(hi, f2);
+        const h2 lo = __builtin_convertvector(r, h2);
+        pk[0][j] = __builtin_bit_cast(unsigned, hi);
+        pk[1][j] = __builtin_bit_cast(unsigned, lo);
     }
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < 2; ++t)
         s.t[t] = make_float4(__uint_as_float(pk[t][0]), __uint_as_float(pk[t][1]), __uint_as_float(pk[t][2]), __uint_as_float(pk[t][3]));
 }
 
@@ -158,10 +155,9 @@ __device__ __forceinline__ void split3(const T16 &x, int p, XSplit &s) {
 // Weight blocks are software pipelined across the whole step: `pre` holds this call's first block(s) (already in flight,
 // issued by the previous call), `next_off` is the start of whatever consumes weights next; the return value is its first
 // block(s), in flight.
-// BF: the products run on the bf16 matrix pipe - x and W as three bf16 terms each, the six products whose terms' indices add
-// up to <= 2 (the dropped three are below 2^-24 of the largest), fp32 accumulation: 12 MFMAs of 32 clocks per 32 x 32 block
-// where the fp32 form takes 16 of 64.  The stream is ordered [kt][k-half p][nt]: half an input tile is split once (12
-// registers) and feeds all output tiles, then the other half.
+// BF ("split"): the products run on the 16-bit matrix pipe - x and W as two fp16 terms each, three products (params_v2.h), fp32
+// accumulation: 6 MFMAs of 32 clocks per 32 x 32 block where the fp32 form takes 16 of 64.  The stream is ordered [kt][k-half p][nt]:
+// half an input tile is split once (8 registers) and feeds all output tiles, then the other half.
 template <int NT, int KT, bool TR, bool BF = false>
 __device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, const T16 (&x)[KT], int lane, WBlk pre,
                                    int next_off) {
@@ -173,28 +169,22 @@ __device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, cons
 #pragma unroll
         for (int i = 0; i < NH; ++i) {
             const int kt = i / (2 * NT), p = (i / NT) % 2, nt = i % NT, d = i % D;
-            if (nt == 0) split3(x[kt], p, xs);
+            if (nt == 0) split2(x[kt], p, xs);
             V2_FENCE();
-            const float4 w0 = q.v[3 * d], w1 = q.v[3 * d + 1], w2 = q.v[3 * d + 2];
-            // smallest products first: W term tw with x terms 2 - tw .. 0
+            const float4 wh = q.v[2 * d], wl = q.v[2 * d + 1];
+            // the two small products first
             if (!TR) {
-                out[nt] = MFMA_BF(as_bf8(w2), as_bf8(xs.t[0]), out[nt]);
-                out[nt] = MFMA_BF(as_bf8(w1), as_bf8(xs.t[1]), out[nt]);
-                out[nt] = MFMA_BF(as_bf8(w1), as_bf8(xs.t[0]), out[nt]);
-                out[nt] = MFMA_BF(as_bf8(w0), as_bf8(xs.t[2]), out[nt]);
-                out[nt] = MFMA_BF(as_bf8(w0), as_bf8(xs.t[1]), out[nt]);
-                out[nt] = MFMA_BF(as_bf8(w0), as_bf8(xs.t[0]), out[nt]);
+                out[nt] = MFMA_H(as_h8(wl), as_h8(xs.t[0]), out[nt]);
+                out[nt] = MFMA_H(as_h8(wh), as_h8(xs.t[1]), out[nt]);
+                out[nt] = MFMA_H(as_h8(wh), as_h8(xs.t[0]), out[nt]);
             } else {
-                out[nt] = MFMA_BF(as_bf8(xs.t[0]), as_bf8(w2), out[nt]);
-                out[nt] = MFMA_BF(as_bf8(xs.t[1]), as_bf8(w1), out[nt]);
-                out[nt] = MFMA_BF(as_bf8(xs.t[0]), as_bf8(w1), out[nt]);
-                out[nt] = MFMA_BF(as_bf8(xs.t[2]), as_bf8(w0), out[nt]);
-                out[nt] = MFMA_BF(as_bf8(xs.t[1]), as_bf8(w0), out[nt]);
-                out[nt] = MFMA_BF(as_bf8(xs.t[0]), as_bf8(w0), out[nt]);
+                out[nt] = MFMA_H(as_h8(xs.t[0]), as_h8(wl), out[nt]);
+                out[nt] = MFMA_H(as_h8(xs.t[1]), as_h8(wh), out[nt]);
+                out[nt] = MFMA_H(as_h8(xs.t[0]), as_h8(wh), out[nt]);
             }
             V2_FENCE();
             // the slot just consumed takes half block i + D of this call, or the next consumer's
-            wload_half(q, d, wp, i + D < NH ? off + (i + D) * V2_HALF_BF3 : next_off + (i + D - NH) * V2_HALF_BF3, lane);
+            wload_half(q, d, wp, i + D < NH ? off + (i + D) * V2_HALF_SPLIT : next_off + (i + D - NH) * V2_HALF_SPLIT, lane);
         }
         // slot d now holds the next consumer's half block (NH + d' ...) - rotate so that its half block 0 sits in slot 0
         if constexpr (NH % D != 0) {
@@ -202,7 +192,7 @@ __device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, cons
 #pragma unroll
             for (int d = 0; d < D; ++d)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) r.v[3 * d + j] = q.v[3 * ((d + NH) % D) + j];
+                for (int j = 0; j < 2; ++j) r.v[2 * d + j] = q.v[2 * ((d + NH) % D) + j];
             return r;
         }
         return q;
@@ -421,7 +411,7 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     T16 whT[1];
     zero(whT);
     const float a_src = gf[lc], a_dst = gf[32 + lc];
-    constexpr int BS = BF ? V2_BLOCK_BF3 : V2_BLOCK_F32;
+    constexpr int BS = BF ? V2_BLOCK_SPLIT : V2_BLOCK_F32;
     pre = mm<1, KT, true, BF>(whT, wp, Gw.heads, x, lane, pre, Gw.out);
     ph(10);
     float u1[16], u2[16];
@@ -528,7 +518,7 @@ template <int KT, int NT, bool BF = false, class AdjFn = void>
 __device__ __forceinline__ WBlk gcn(const T16 (&x)[KT], T16 (&out)[NT], const WBuf &wp, const V2Gat &Gw, AdjFn adjv, int lane,
                                     WBlk pre, int next_off) {
     const int lh = lane >> 5;
-    constexpr int BS = BF ? V2_BLOCK_BF3 : V2_BLOCK_F32;
+    constexpr int BS = BF ? V2_BLOCK_SPLIT : V2_BLOCK_F32;
     T16 whT[1];
     zero(whT);
     pre = mm<1, KT, true, BF>(whT, wp, Gw.heads, x, lane, pre, Gw.out);
@@ -641,7 +631,7 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
         // gates one after the other so that only one accumulator plus two 16-register results are live:
         //   nh -> r -> t = r*(W_hn h + b_hn) -> n = tanh(W_in x + b_in + t) -> z -> h' = (1-z) n + z h
         // weights of a gate are packed per output tile: offset of tile nt = nt * KT * 1024 floats
-        constexpr int BS = BF ? V2_BLOCK_BF3 : V2_BLOCK_F32;
+        constexpr int BS = BF ? V2_BLOCK_SPLIT : V2_BLOCK_F32;
         const int ox = nt * KX * BS, oh = nt * 2 * BS;
         T16 acc[1], tt, ng;
         init(acc[0], 0, Gw.nh.bias, nt);

@@ -1,3 +1,4 @@
+// (round 3: + MODE 4 = fp16 two terms, three products)
 // What would the rollout's dense layers cost, and how exact would they be, on split-bf16 products instead of the fp32 MFMA?
 // (the fp32 v_mfma_f32_32x32x2_f32 takes 64 clocks and blocks vector issue; the bf16 32x32x16 form takes 32.)
 // One wave = one 32-row tile running a chain of L layers x <- relu(W x), W 64 x 64 in LDS, activations register-resident in
@@ -17,6 +18,9 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 // LDS images.  fp32: [mt 2][q 8][lane 64] float4, q = 4 nt_in + a, element i = W[32mt + m][32nt_in + 8a + 4lh + i].
 // bf16: [term 3][mt 2][kb 4][lane 64] 8 x bf16, kb = 2 nt_in + p, slot j = W[32mt + m][32nt_in + 8(2p + j/4) + 4lh + j%4].
@@ -27,7 +31,7 @@ template <int MODE, int SPLIT>
 __global__ __launch_bounds__(512) void chain(const float *__restrict__ img, const float *__restrict__ X, float *__restrict__ Y,
                                              int layers, unsigned long long *ticks) {
     extern __shared__ float lds[];
-    constexpr int IMG = MODE == 0 ? F32_IMG : BF_IMG;
+    constexpr int IMG = MODE == 0 ? F32_IMG : BF_IMG;      // (MODE 4 uses two of the three term planes)
     for (int i = threadIdx.x; i < IMG; i += blockDim.x) lds[i] = img[i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -56,6 +60,37 @@ __global__ __launch_bounds__(512) void chain(const float *__restrict__ img, cons
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[i], b, acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[i], b, acc[1], 0, 0, 0);
                 }
+            }
+        } else if constexpr (MODE == 4) {
+            // fp16, two terms (11 + 11 significant bits, round to nearest), three products (hh, hl, lh)
+            const uint4 *w = reinterpret_cast<const uint4 *>(lds);
+            uint4 xh[4], xl[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                unsigned ph[4], pl[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f2 v = {x[kb >> 1][8 * (kb & 1) + 2 * j], x[kb >> 1][8 * (kb & 1) + 2 * j + 1]};
+                    const h2 hi = __builtin_convertvector(v, h2);
+                    const f2 r = v - __builtin_convertvector(hi, f2);
+                    const h2 lo = __builtin_convertvector(r, h2);
+                    ph[j] = __builtin_bit_cast(unsigned, hi);
+                    pl[j] = __builtin_bit_cast(unsigned, lo);
+                }
+                xh[kb] = uint4{ph[0], ph[1], ph[2], ph[3]};
+                xl[kb] = uint4{pl[0], pl[1], pl[2], pl[3]};
+            }
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                const f16x8 w0h = __builtin_bit_cast(f16x8, w[((0 * 2 + 0) * 4 + kb) * 64 + lane]), w1h = __builtin_bit_cast(f16x8, w[((0 * 2 + 1) * 4 + kb) * 64 + lane]);
+                const f16x8 w0l = __builtin_bit_cast(f16x8, w[((1 * 2 + 0) * 4 + kb) * 64 + lane]), w1l = __builtin_bit_cast(f16x8, w[((1 * 2 + 1) * 4 + kb) * 64 + lane]);
+                const f16x8 bh = __builtin_bit_cast(f16x8, xh[kb]), bl = __builtin_bit_cast(f16x8, xl[kb]);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0l, bh, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1l, bh, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, bl, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bl, acc[1], 0, 0, 0);
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0h, bh, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1h, bh, acc[1], 0, 0, 0);
             }
         } else {
             constexpr int NT = MODE;                 // terms kept of x and of W
@@ -154,6 +189,19 @@ void run(const char *name, const std::vector<float> &W, const std::vector<float>
                     for (int i = 0; i < 4; ++i)
                         img[((mt * 8 + q) * 64 + lane) * 4 + i] =
                             W[(32 * mt + (lane & 31)) * 64 + 32 * (q >> 2) + 8 * (q & 3) + 4 * (lane >> 5) + i];
+    } else if (MODE == 4) {
+        _Float16 *h = reinterpret_cast<_Float16 *>(img.data());
+        for (int mt = 0; mt < 2; ++mt)
+            for (int kb = 0; kb < 4; ++kb)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        float v = W[(32 * mt + (lane & 31)) * 64 + 32 * (kb >> 1) + 8 * (2 * (kb & 1) + j / 4) + 4 * (lane >> 5) + j % 4];
+                        for (int t = 0; t < 2; ++t) {
+                            const _Float16 b = (_Float16)v;
+                            h[((((t * 2 + mt) * 4 + kb) * 64 + lane) * 8) + j] = b;
+                            v -= (float)b;
+                        }
+                    }
     } else {
         unsigned short *h = reinterpret_cast<unsigned short *>(img.data());
         for (int mt = 0; mt < 2; ++mt)
@@ -234,5 +282,6 @@ int main() {
     run<2>("bf16 x2 (three products)", W, X, cur, rows);
     run<3, 2>("bf16 x3, truncating split", W, X, cur, rows);
     run<3, 0>("bf16 x3 without the split", W, X, cur, rows);
+    run<4>("fp16 x2 (three products)", W, X, cur, rows);
     return 0;
 }

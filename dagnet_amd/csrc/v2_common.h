@@ -122,7 +122,10 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f16x8 as_h8(float4 v) { return __builtin_bit_cast(f16x8, v); }
 
 // Registers 8p .. 8p+7 of an S- or T-layout tile as two fp16 terms, rounded to nearest: hi = fp16(v), lo = fp16(v - hi) (the
-// difference is exact in fp32) - per pair of values v_cvt_pk_f16_f32, two v_cvt_f32_f16, v_pk_add_f32, v_cvt_pk_f16_f32.
+// difference is exact in fp32) - THREE instructions per pair of values: v_cvt_pk_f16_f32 for the two hi terms, then
+// v_fma_mixlo_f16 / v_fma_mixhi_f16, which read a half of the packed hi as fp16, compute v - hi in fp32 and write the rounded fp16
+// into the low / high half of the packed lo (the compiler's own form of the same arithmetic takes five: two v_cvt_f32_f16, a
+// v_pk_add_f32, a v_cvt_pk_f16_f32; DN_V2_SPLIT_C selects it).
 // t[term] = the 8 k-slots of one v_mfma_f32_32x32x16_f16 operand (slot s = register 8p + s: the order the weights are packed in).
 // The values are read through an opaque copy: left alone, the compiler recognises the split of a tile that several products
 // read (h, phi_z, the GRU's inputs) as a common subexpression and keeps its registers alive from the first use to the last -
@@ -140,10 +143,17 @@ __device__ __forceinline__ void split2(const T16 &x, int p, XSplit &s) {
         asm volatile("" : "+v"(v0), "+v"(v1));
         const f2 v = {v0, v1};
         const h2 hi = __builtin_convertvector(v, h2);
+        pk[0][j] = __builtin_bit_cast(unsigned, hi);
+#ifdef DN_V2_SPLIT_C
         const f2 r = v - __builtin_convertvector(hi, f2);
         const h2 lo = __builtin_convertvector(r, h2);
-        pk[0][j] = __builtin_bit_cast(unsigned, hi);
         pk[1][j] = __builtin_bit_cast(unsigned, lo);
+#else
+        unsigned lo;
+        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(pk[0][j]), "v"(v0));
+        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(pk[0][j]), "v"(v1));
+        pk[1][j] = lo;
+#endif
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -234,6 +244,23 @@ __device__ __forceinline__ WBlk mm(T16 (&out)[NT], const WBuf &wp, int off, cons
 #endif
     }
     return q0;
+    }
+}
+
+// acc += A . B for two register tiles on the 16-bit matrix pipe: A (already split: a[k-half]) supplies lane = output feature,
+// slots = the 32 contraction rows; b (split here) lane = output column.  The graph layers' per-scene aggregation out^T = Wh^T alpha^T.
+__device__ __forceinline__ void split_tile(const T16 &x, XSplit (&s)[2]) {
+    split2(x, 0, s[0]);
+    split2(x, 1, s[1]);
+}
+__device__ __forceinline__ void agg_split(T16 &acc, const XSplit (&a)[2], const T16 &b) {
+    XSplit bs[2];
+    split_tile(b, bs);
+#pragma unroll
+    for (int kh = 0; kh < 2; ++kh) {
+        acc = MFMA_H(as_h8(a[kh].t[1]), as_h8(bs[kh].t[0]), acc);
+        acc = MFMA_H(as_h8(a[kh].t[0]), as_h8(bs[kh].t[1]), acc);
+        acc = MFMA_H(as_h8(a[kh].t[0]), as_h8(bs[kh].t[0]), acc);
     }
 }
 
@@ -445,6 +472,8 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     T16 x2[1];
     zero(x2);
     float inv[4];
+    XSplit whs[2];
+    if constexpr (BF) split_tile(whT[0], whs);
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         float s2[16];
@@ -452,9 +481,21 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
         for (int r = 0; r < 16; ++r) s2[r] = xch[p * 32 + FR(r) + 4 * lh];
         T16 alpha;
         inv[p] = attn_weights<false>(alpha, s1[p], s2, mb, slope);
-        const bool mine = (lc >> 3) == p;     // this lane's feature belongs to head p
+        if constexpr (BF) {
+            // the product of ALL 32 head features with head p's attention weights; its registers 4p .. 4p+3 are head p's features
+            // 8p .. 8p+7 of this lane's row (the other twelve belong to other heads' attention and are dropped) - six 32-clock
+            // MFMAs per head where the masked fp32 form took sixteen of 64
+            T16 dp;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x2[0] = MFMA(mine ? whT[0][r] : 0.f, alpha[r], x2[0]);
+            for (int r = 0; r < 16; ++r) dp[r] = 0.f;
+            agg_split(dp, whs, alpha);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) x2[0][4 * p + i] = dp[4 * p + i];
+        } else {
+            const bool mine = (lc >> 3) == p;     // this lane's feature belongs to head p
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x2[0] = MFMA(mine ? whT[0][r] : 0.f, alpha[r], x2[0]);
+        }
     }
     ph(12);
     // head p's features 8p .. 8p+7 are registers 4p .. 4p+3 of this lane's row: its softmax denominator is applied here
@@ -491,8 +532,14 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
         T16 wh2T[1];
         zero(wh2T);
         pre = mm<1, 1, true, BF>(wh2T, wp, Gw.out + nt * BS, x2, lane, pre, nt + 1 < NT ? Gw.out + (nt + 1) * BS : next_off);
+        if constexpr (BF) {
+            XSplit w2s[2];
+            split_tile(wh2T[0], w2s);
+            agg_split(out[nt], w2s, alpha);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], alpha[r], out[nt]);
+            for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], alpha[r], out[nt]);
+        }
     }
     ph(14);
     // tanh; padded features (weights and shift 0) stay 0
@@ -525,10 +572,18 @@ __device__ __forceinline__ WBlk gcn(const T16 (&x)[KT], T16 (&out)[NT], const WB
     float av[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) av[r] = adjv(r);
-    T16 x1[1];
+    T16 x1[1], avt;
     zero(x1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) x1[0] = MFMA(whT[0][r], av[r], x1[0]);
+    for (int r = 0; r < 16; ++r) avt[r] = av[r];
+    if constexpr (BF) {
+        XSplit whs[2];
+        split_tile(whT[0], whs);
+        agg_split(x1[0], whs, avt);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x1[0] = MFMA(whT[0][r], av[r], x1[0]);
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
         const float4 sc = wp.ld4(lh * 16, Gw.fold + 8 * a), sh = wp.ld4(lh * 16, Gw.fold + 32 + 8 * a);
@@ -541,8 +596,14 @@ __device__ __forceinline__ WBlk gcn(const T16 (&x)[KT], T16 (&out)[NT], const WB
         T16 wh2T[1];
         zero(wh2T);
         pre = mm<1, 1, true, BF>(wh2T, wp, Gw.out + nt * BS, x1, lane, pre, nt + 1 < NT ? Gw.out + (nt + 1) * BS : next_off);
+        if constexpr (BF) {
+            XSplit w2s[2];
+            split_tile(wh2T[0], w2s);
+            agg_split(out[nt], w2s, avt);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], av[r], out[nt]);
+            for (int r = 0; r < 16; ++r) out[nt] = MFMA(wh2T[0][r], av[r], out[nt]);
+        }
     }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)

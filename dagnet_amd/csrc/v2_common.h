@@ -122,10 +122,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f16x8 as_h8(float4 v) { return __builtin_bit_cast(f16x8, v); }
 
 // Registers 8p .. 8p+7 of an S- or T-layout tile as two fp16 terms, rounded to nearest: hi = fp16(v), lo = fp16(v - hi) (the
-// difference is exact in fp32) - THREE instructions per pair of values: v_cvt_pk_f16_f32 for the two hi terms, then
-// v_fma_mixlo_f16 / v_fma_mixhi_f16, which read a half of the packed hi as fp16, compute v - hi in fp32 and write the rounded fp16
-// into the low / high half of the packed lo (the compiler's own form of the same arithmetic takes five: two v_cvt_f32_f16, a
-// v_pk_add_f32, a v_cvt_pk_f16_f32; DN_V2_SPLIT_C selects it).
+// difference is exact in fp32) - five instructions per pair of values: v_cvt_pk_f16_f32 for the two hi terms, two v_cvt_f32_f16,
+// a v_pk_add_f32, a v_cvt_pk_f16_f32.
+// (Three would do - v_fma_mixlo_f16 / v_fma_mixhi_f16 read a half of the packed hi as fp16, compute v - hi in fp32 and write the
+// rounded fp16 into one half of the packed lo; the compiler does not select them for this arithmetic, and as INLINE ASM they are
+// invisible to its hazard recognizer: it pads VALU instructions that touch a register an MFMA is still writing with s_nop, inline
+// asm it does not.  Built that way (DN_V2_SPLIT_MIX) the kernels were 2 % faster and ONE instantiation - DAG-Net, one GRU layer, GCN -
+// produced trajectories 1e-2 off from the second step on, in one particular schedule only.  Not used.)
 // t[term] = the 8 k-slots of one v_mfma_f32_32x32x16_f16 operand (slot s = register 8p + s: the order the weights are packed in).
 // The values are read through an opaque copy: left alone, the compiler recognises the split of a tile that several products
 // read (h, phi_z, the GRU's inputs) as a common subexpression and keeps its registers alive from the first use to the last -
@@ -144,7 +147,7 @@ __device__ __forceinline__ void split2(const T16 &x, int p, XSplit &s) {
         const f2 v = {v0, v1};
         const h2 hi = __builtin_convertvector(v, h2);
         pk[0][j] = __builtin_bit_cast(unsigned, hi);
-#ifdef DN_V2_SPLIT_C
+#ifndef DN_V2_SPLIT_MIX
         const f2 r = v - __builtin_convertvector(hi, f2);
         const h2 lo = __builtin_convertvector(r, h2);
         pk[1][j] = __builtin_bit_cast(unsigned, lo);
@@ -282,11 +285,31 @@ __device__ __forceinline__ void add_vec(T16 (&x)[NT], const WBuf &wp, int off, i
 // ACT: 0 none, 1 LeakyReLU(0.01), 2 ReLU
 template <int ACT, int NT>
 __device__ __forceinline__ void activate(T16 (&x)[NT]) {
-    if (ACT != 0) {
+#ifdef DN_V2_NO_PKLRELU
+    if (ACT == 1) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) x[nt][r] = ACT == 1 ? lrelu(x[nt][r], 0.01f) : fmaxf(x[nt][r], 0.f);
+            for (int r = 0; r < 16; ++r) x[nt][r] = lrelu(x[nt][r], 0.01f);
+        return;
+    }
+#endif
+    if (ACT == 1) {         // LeakyReLU(0.01) = max(v, 0.01 v): the products as v_pk_mul_f32 (two per instruction), then one v_max each
+        typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const f2 v = {x[nt][r], x[nt][r + 1]};
+                const f2 m = v * f2{0.01f, 0.01f};
+                x[nt][r] = __builtin_amdgcn_fmed3f(v.x, m.x, INFINITY);
+                x[nt][r + 1] = __builtin_amdgcn_fmed3f(v.y, m.y, INFINITY);
+            }
+    } else if (ACT != 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) x[nt][r] = fmaxf(x[nt][r], 0.f);
     }
 }
 // The same vector as the INITIAL value of the layer's accumulators instead of an addition after its MFMAs: the loads are

@@ -32,9 +32,12 @@ from dagnet_amd import _capi, synthetic as syn       # noqa: E402
 from dagnet_amd._runtime import scene_ptr_from_sse   # noqa: E402
 
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
-# The wide layers of the g_dim = 960 goal head multiply on the bf16 matrix pipe: three bf16 terms per fp32 value, six bf16 products
-# per fp32 product (csrc/gemm_f32.hip, BF3).  Their bound in fp32-equivalent FLOP/s is the dense bf16 peak (2.5 PFLOP/s) / 6.
-PEAK_SPLIT_BF16_TFLOPS = 2500.0 / 6.0
+# Split products on the 16-bit matrix pipe, fp32 in / fp32 out / fp32 accumulation.  Their bound in fp32-equivalent
+# FLOP/s is the dense 16-bit peak (2.5 PFLOP/s) over the 16-bit products one fp32 product costs:
+#   register-resident rollout kernels (csrc/v2_common.h mm<..., BF>): two fp16 terms per value, three products (hh, hl, lh);
+#   wide layers of the g_dim = 960 goal head (csrc/gemm_f32.hip, BF3): three bf16 terms per value, six products.
+PEAK_SPLIT_FP16X2_TFLOPS = 2500.0 / 3.0
+PEAK_SPLIT_BF16X3_TFLOPS = 2500.0 / 6.0
 
 
 def pmc_traffic(workload, kernel):
@@ -596,18 +599,24 @@ def main():
             launch_flop /= n_chunks
         achieved = launch_flop / (kernel_ms * 1e-3) / 1e12
         info = model.hip_plan(dev, np.ascontiguousarray(plan_sp - plan_sp[0]), K).info()
-        # the dense products of the register-resident kernels and of the wide goal head run on the bf16 matrix pipe (three bf16
-        # terms per fp32 value, six products) unless switched off; the generic kernels always use fp32 MFMAs
+        # the dense products of the register-resident kernels (fp16 x2) and of the wide goal head (bf16 x3: the launch's dominant
+        # kernel there) run on the 16-bit matrix pipe unless switched off; the generic kernels always use fp32 MFMAs
         from dagnet_amd import _ops
-        split_bf16 = ("wide goal head" in info["sample_kernel"] or "register-resident" in info["sample_kernel"]) and bool(_ops.set_fused(-1) & 8)
-        peak = PEAK_SPLIT_BF16_TFLOPS if split_bf16 else PEAK_FP32_MATRIX_TFLOPS
+        split_on = bool(_ops.set_fused(-1) & 8)
+        split = None
+        if split_on and "wide goal head" in info["sample_kernel"]:
+            split = ("bf16x3", PEAK_SPLIT_BF16X3_TFLOPS, "bf16 dense / 6 products (three bf16 terms per value; wide layers)")
+        elif split_on and "register-resident" in info["sample_kernel"]:
+            split = ("fp16x2", PEAK_SPLIT_FP16X2_TFLOPS, "fp16 dense / 3 products (two fp16 terms per value)")
+        split_bf16 = split is not None
+        peak = split[1] if split else PEAK_FP32_MATRIX_TFLOPS
         line = {
             "metric": "sampled trajectories/sec (best-of-20 rollout)", "value": value, "unit": "trajectories/s",
             "n_gpus": world_seen, "steps": opt.steps, "warmup": opt.warmup, "ms_per_step": dt / opt.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            # fp32 in, fp32 out, fp32 accumulation; where the products run on the bf16 matrix pipe (three bf16 terms per fp32
-            # value, six products: error <= the fp32 MFMA's) the label says so
-            "dtype": "f32 (bf16x3 products)" if split_bf16 else "f32", "data": "synthetic",
+            # fp32 in, fp32 out, fp32 accumulation; where the products run on the 16-bit matrix pipe as split terms (error of the
+            # fp32 MFMA's class, tests/test_gpu_properties.py) the label says so
+            "dtype": f"f32 ({split[0]} products)" if split else "f32", "data": "synthetic",
             "config": {"workload": opt.workload, "model": wl["kind"], "scenes_per_gpu": S, "agents_per_scene": n,
                        "samples": K, "obs_len": wl["obs"], "pred_len": T, "rows_per_gpu": n_rows * K,
                        "chunks_per_step": n_chunks, "scenes_per_chunk": chunk,
@@ -615,7 +624,7 @@ def main():
                        "parallelism": f"scenes sharded x{world_seen}, 1 all-reduce of 3 doubles per step"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                          "frac": achieved / peak,
-                         "peak_kind": "bf16 dense / 6 products (split-bf16 wide layers)" if split_bf16 else "fp32 matrix",
+                         "peak_kind": split[2] if split else "fp32 matrix",
                          "traffic": pmc_traffic("dagnet_bsk_4096x20" if strong else opt.workload, info["sample_kernel"]),
                          "kernel": info["sample_kernel"], "kernel_ms": kernel_ms,
                          "flop_per_trajectory": fl},

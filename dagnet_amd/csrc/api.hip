@@ -97,8 +97,8 @@ struct dagnet_model {
     size_t wp_floats = 0;
     int device = 0;
     bool v2 = false;            // the register-resident kernel (rollout_v2.hip) covers this model
-    // two v2 regions: [0] fp32 MFMA blocks (the teacher-forced kernels, and the rollout when split-bf16 is switched off),
-    // [1] split-bf16 blocks (the rollout kernels' default)
+    // two v2 regions: [0] fp32 MFMA blocks (the teacher-forced kernels, and the rollout when split products are switched off),
+    // [1] split fp16 blocks (the rollout kernels' default)
     V2Weights w2[2];            // absolute offsets into d_wp (read by model 3 only: wide goal head)
     V2Weights *d_w2[2] = {nullptr, nullptr};  // device copies of w2
     int v2_base[2] = {0, 0};    // start of the v2 regions in d_wp: the v2 kernels use compile-time offsets relative to them
@@ -244,7 +244,7 @@ struct Packer {
         return off;
     }
     bool split_overflow = false;      // a weight beyond the fp16 range (or not finite): the model keeps the fp32 kernels
-    // the v2 regions' dense segments: fp32 chain order or split-bf16 blocks, as the region being packed says
+    // the v2 regions' dense segments: fp32 chain order or split fp16 blocks, as the region being packed says
     int chain_v2(const WFn &W, int N, int K, bool kt_major) { return bf ? chain_split(W, N, K, kt_major) : chain(W, N, K); }
     // plain row-major [N][ld] (ld >= K, zero padded): operands of the batched GEMMs (gemm_f32.hip)
     int rowmajor(const WFn &W, int N, int K, int ld) {
@@ -604,7 +604,7 @@ void v2_gcn(Packer &pk, V2Gat &g, const std::string &prefix, int nin, int nout, 
 }
 
 // part 0: the six weight segments in the order the kernels' GRU consumes them (nh, r.x, r.h, ni, z.x, z.h); part 1: biases.
-// fp32 blocks are [nt][kt] (one output tile per product); split-bf16 ones [kt][p][nt] (both output tiles per product:
+// fp32 blocks are [nt][kt] (one output tile per product); split fp16 ones [kt][p][nt] (both output tiles per product:
 // v2_common.h gru<>, BF).
 void v2_gru(Packer &pk, V2Gru &g, int l, int R, int H, int part) {
     const int Kin = l == 0 ? 2 * H : R;
@@ -618,7 +618,7 @@ void v2_gru(Packer &pk, V2Gru &g, int l, int R, int H, int part) {
     // gate pre-activations come out already scaled for sigm2() / tanh2() (v2_common.h): r, z by -log2(e); both halves of
     // the candidate (W_in x + b_in and W_hn h + b_hn, the latter multiplied by r in between) by 2 log2(e)
     if (pk.bf && part == 0) {
-        // split-bf16 kernels (v2_common.h gru<>, BF): two dense layers with 3 R outputs each - W_ih with its gates in the order
+        // split-product kernels (v2_common.h gru<>, BF): two dense layers with 3 R outputs each - W_ih with its gates in the order
         // n, r, z and W_hh in the order r, z, n - so that an input tile is split once for all gates
         const int gx[3] = {2, 0, 1}, gh[3] = {0, 1, 2};
         auto scale = [](int gate) { return gate == 2 ? kTanhScale : kSigmScale; };
@@ -841,7 +841,7 @@ std::string v2_check_layout(const V2Weights &W, int base, int total, int model_c
 // C ABI
 // ---------------------------------------------------------------------------------------------
 extern "C" const char *dagnet_last_error(void) { return g_err; }
-extern "C" const char *dagnet_version(void) { return "dagnet_hip 0.3 (gfx950, split-bf16 32x32x16 + fp32 32x32x2 MFMA)"; }
+extern "C" const char *dagnet_version(void) { return "dagnet_hip 0.3 (gfx950, split fp16x2 / bf16x3 32x32x16 + fp32 32x32x2 MFMA)"; }
 
 extern "C" int dagnet_model_create(const dagnet_config *cfg, const dagnet_tensor *tensors, int32_t n_tensors, dagnet_model **out) {
     if (!cfg || !out || (!tensors && n_tensors > 0)) return fail(DAGNET_ERR_INVALID, "null argument");

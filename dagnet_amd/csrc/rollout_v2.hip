@@ -27,8 +27,8 @@ namespace v2 {
 // step is read from the per-sample goal state; state is per (sample, row) and written back after the last step).
 // NL: GRU layers.  ZT: 32 -> z_dim 32, 16 -> z_dim 16.
 // GM: 1 = GAT (4 heads x 8), 2 = GCN (graph_hid <= 32).
-// BF: dense products on the bf16 matrix pipe (three bf16 terms per fp32 value, v2_common.h mm<..., BF>); weights from the
-// split-bf16 region of the model (params_v2.h).
+// BF: dense and graph products on the 16-bit matrix pipe (two fp16 terms per fp32 value, three products: v2_common.h
+// mm<..., BF>); weights from the split region of the model (params_v2.h).
 #ifndef DN_V2_OCC
 #define DN_V2_OCC 2       // waves per SIMD the register budget is cut for
 #endif
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64, DN_V2_OCC) void rollout_v2_kernel(const V2Weigh
     // DAG-Net: hidden state parked in LDS while the goal head needs the registers ([tile][reg][lane], conflict free)
     // also (NL == 2): the top layer's state is parked while GRU layer 0 runs (its 4 input tiles + 2 state tiles + gate
     // temporaries do not fit beside it; the compiler would spill ~140 registers to scratch memory instead)
-    // split-bf16 kernels: every layer's state has its slot (a GRU layer parks its state there while it multiplies its inputs)
+    // split-product kernels: every layer's state has its slot (a GRU layer parks its state there while it multiplies its inputs)
     __shared__ float stash[(MODEL == 2 || MODEL == 4 || BF) ? NL * 32 * 64 : (NL == 2 ? 32 * 64 : 1)];
     __shared__ float gbias[NL * GRU_BIAS_FLOATS];      // GRU gate biases (v2_common.h gru_bias_to_lds)
     float *pos = xch + 128;                 // [32][2] current absolute positions of the tile rows
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(64, DN_V2_OCC) void rollout_v2_kernel(const V2Weigh
 }   // namespace v2
 
 // This file is compiled twice (Makefile): DN_V2_BF = 0 -> the fp32-MFMA kernels (dn_launch_rollout_v2), DN_V2_BF = 1 -> the
-// split-bf16 ones (dn_launch_rollout_v2_bf3); one translation unit each so that the two sets build in parallel.
+// split-product ones (dn_launch_rollout_v2_bf3); one translation unit each so that the two sets build in parallel.
 #ifndef DN_V2_BF
 #define DN_V2_BF 0
 #endif

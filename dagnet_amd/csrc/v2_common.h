@@ -672,7 +672,7 @@ __device__ __forceinline__ WBlk gru(const T16 (&xin)[KX], T16 (&h)[2], const WBu
         }
     };
     if constexpr (BF) {
-        // split-bf16 products: the GRU as two dense layers with six output tiles each, so that every input tile is split once -
+        // split products: the GRU as two dense layers with six output tiles each, so that every input tile is split once -
         //   X phase: [ni | r | z] += W_ih x      (g[0..5], stream Gw.r.w[0]: rows n, r, z of weight_ih, [kt][p][6 tiles])
         //   H phase: [r | z | nh] += W_hh h      (g[2..7], stream Gw.r.w[1]: rows r, z, n of weight_hh)
         // h is not read in the X phase: with `park` (16 x 64 floats per tile of LDS, [tile][reg][lane]) it waits there.

@@ -260,10 +260,12 @@ int dagnet_op_linear_pieces_bwd(int64_t M, const float *dy, int64_t lddy, const 
                                 int32_t cA, int32_t KA, int32_t accA, float *dxB, int64_t lddxB, int32_t cB, int32_t KB, int32_t accB,
                                 void *stream);
 /* Selects the fused training kernels at run time: bit 0 = dagnet_op_gru_layer_fwd's one-kernel form, bit 1 = dagnet_op_mlp_chain_fwd's,
- * bit 2 = dagnet_op_mlp2_bwd's (a cleared bit makes the entry point take its layer-by-layer form / return 1); bit 3 = split-bf16
- * products (three bf16 terms per fp32 value, six matrix-core products, fp32 accumulation: fp32-class error) in the wide layers
- * (more than 96 outputs) of dagnet_op_gemm and of the g_dim = 960 goal head, AND in every dense product of the register-resident
- * rollout kernels behind dagnet_sample (csrc/rollout_v2.hip; cleared: the fp32-MFMA kernels of rounds 1-2); mask < 0 restores the default (all on, minus
+ * bit 2 = dagnet_op_mlp2_bwd's (a cleared bit makes the entry point take its layer-by-layer form / return 1); bit 3 = split
+ * products on the 16-bit matrix pipe, fp32 in / out / accumulation, fp32-MFMA-class error: three bf16 terms per value and six
+ * products in the wide layers (more than 96 outputs) of dagnet_op_gemm and of the g_dim = 960 goal head; two fp16 terms per value
+ * and three products in every dense and graph product of the register-resident rollout kernels behind dagnet_sample
+ * (csrc/rollout_v2.hip; a model with a weight beyond fp16's range keeps the fp32-MFMA kernels, which are also what a cleared
+ * bit selects); mask < 0 restores the default (all on, minus
  * DAGNET_NO_GRU_FUSED / DAGNET_NO_MLP_FUSED / DAGNET_NO_MLP_BWD_FUSED / DAGNET_NO_BF16X3).  -> the previous mask.
  * No counterpart in the reference: a switch for A/B comparisons and tests. */
 int dagnet_op_set_fused(int32_t mask);

@@ -122,13 +122,16 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f16x8 as_h8(float4 v) { return __builtin_bit_cast(f16x8, v); }
 
 // Registers 8p .. 8p+7 of an S- or T-layout tile as two fp16 terms, rounded to nearest: hi = fp16(v), lo = fp16(v - hi) (the
-// difference is exact in fp32) - five instructions per pair of values: v_cvt_pk_f16_f32 for the two hi terms, two v_cvt_f32_f16,
-// a v_pk_add_f32, a v_cvt_pk_f16_f32.
-// (Three would do - v_fma_mixlo_f16 / v_fma_mixhi_f16 read a half of the packed hi as fp16, compute v - hi in fp32 and write the
-// rounded fp16 into one half of the packed lo; the compiler does not select them for this arithmetic, and as INLINE ASM they are
-// invisible to its hazard recognizer: it pads VALU instructions that touch a register an MFMA is still writing with s_nop, inline
-// asm it does not.  Built that way (DN_V2_SPLIT_MIX) the kernels were 2 % faster and ONE instantiation - DAG-Net, one GRU layer, GCN -
-// produced trajectories 1e-2 off from the second step on, in one particular schedule only.  Not used.)
+// difference is exact in fp32) - three instructions per pair of values: v_cvt_pk_f16_f32 for the two hi terms, then v_fma_mixlo_f16 /
+// v_fma_mixhi_f16, which read one half of the packed hi as fp16, compute hi * (-1) + v in fp32 and write the rounded fp16 into one
+// half of the packed lo.  The compiler selects them for fptrunc(fma(fpext(hi), m, v)) only if (a) the multiplier is not a
+// constant it can fold (v - hi as an fsub becomes two v_cvt_f32_f16 + a v_pk_add_f32 + a v_cvt_pk_f16_f32: five instructions per
+// pair, DN_V2_SPLIT_SUB) - hence the opaque -1.0 in an SGPR - and (b) the SLP vectoriser does not pair the two fmas into one
+// v_pk_fma_f32 - hence the opaque copy of the low half between them.  1 215 fewer VALU instructions per wave-step of the DAG-Net
+// kernel (10 024 -> 8 774), 42.1 -> 40.1 ms per launch.
+// (The same two instructions written as INLINE ASM were tried first and are gone: inline asm is invisible to the compiler's hazard
+// recognizer, which pads a VALU write that an MFMA reads next with s_nop - 531 of them per step in the compiler-visible form, 367
+// with the asm - and ONE instantiation - DAG-Net, one GRU layer, GCN - produced trajectories 1e-2 off from the second step on.)
 // t[term] = the 8 k-slots of one v_mfma_f32_32x32x16_f16 operand (slot s = register 8p + s: the order the weights are packed in).
 // The values are read through an opaque copy: left alone, the compiler recognises the split of a tile that several products
 // read (h, phi_z, the GRU's inputs) as a common subexpression and keeps its registers alive from the first use to the last -
@@ -136,27 +139,38 @@ __device__ __forceinline__ f16x8 as_h8(float4 v) { return __builtin_bit_cast(f16
 struct XSplit {
     float4 t[2];
 };
+__device__ __forceinline__ float split_m1() {
+    float m = -1.0f;
+    asm volatile("" : "+s"(m));
+    return m;
+}
 __device__ __forceinline__ void split2(const T16 &x, int p, XSplit &s) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     unsigned pk[2][4];
+#ifndef DN_V2_SPLIT_SUB
+    const float m1 = split_m1();
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float v0 = x[8 * p + 2 * j], v1 = x[8 * p + 2 * j + 1];
+#ifndef DN_V2_SPLIT_NOCOPY
         asm volatile("" : "+v"(v0), "+v"(v1));
+#endif
         const f2 v = {v0, v1};
         const h2 hi = __builtin_convertvector(v, h2);
         pk[0][j] = __builtin_bit_cast(unsigned, hi);
-#ifndef DN_V2_SPLIT_MIX
+#ifndef DN_V2_SPLIT_SUB
+        h2 lo;
+        _Float16 l0 = (_Float16)__builtin_fmaf((float)hi[0], m1, v0);
+        asm("" : "+v"(l0));
+        lo[0] = l0;
+        lo[1] = (_Float16)__builtin_fmaf((float)hi[1], m1, v1);
+#else
         const f2 r = v - __builtin_convertvector(hi, f2);
         const h2 lo = __builtin_convertvector(r, h2);
-        pk[1][j] = __builtin_bit_cast(unsigned, lo);
-#else
-        unsigned lo;
-        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(pk[0][j]), "v"(v0));
-        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(pk[0][j]), "v"(v1));
-        pk[1][j] = lo;
 #endif
+        pk[1][j] = __builtin_bit_cast(unsigned, lo);
     }
 #pragma unroll
     for (int t = 0; t < 2; ++t)

@@ -35,7 +35,8 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, "P
 # Split products on the 16-bit matrix pipe, fp32 in / fp32 out / fp32 accumulation.  Their bound in fp32-equivalent
 # FLOP/s is the dense 16-bit peak (2.5 PFLOP/s) over the 16-bit products one fp32 product costs:
 #   register-resident rollout kernels (csrc/v2_common.h mm<..., BF>): two fp16 terms per value, three products (hh, hl, lh);
-#   wide layers of the g_dim = 960 goal head (csrc/gemm_f32.hip, BF3): three bf16 terms per value, six products.
+#   wide layers of the g_dim = 960 goal head (csrc/gemm_f32.hip, SPLIT = 2): the same since round 3; three bf16 terms per value and
+#   six products (SPLIT = 3) in dagnet_op_gemm's wide layers and under DAGNET_WIDE_BF16X3.
 PEAK_SPLIT_FP16X2_TFLOPS = 2500.0 / 3.0
 PEAK_SPLIT_BF16X3_TFLOPS = 2500.0 / 6.0
 
@@ -599,13 +600,15 @@ def main():
             launch_flop /= n_chunks
         achieved = launch_flop / (kernel_ms * 1e-3) / 1e12
         info = model.hip_plan(dev, np.ascontiguousarray(plan_sp - plan_sp[0]), K).info()
-        # the dense products of the register-resident kernels (fp16 x2) and of the wide goal head (bf16 x3: the launch's dominant
-        # kernel there) run on the 16-bit matrix pipe unless switched off; the generic kernels always use fp32 MFMAs
+        # the dense products of the register-resident kernels and of the wide goal head (fp16 x2) run on the 16-bit matrix pipe
+        # unless switched off; the generic kernels always use fp32 MFMAs
         from dagnet_amd import _ops
         split_on = bool(_ops.set_fused(-1) & 8)
         split = None
-        if split_on and "wide goal head" in info["sample_kernel"]:
+        if split_on and "wide goal head" in info["sample_kernel"] and os.environ.get("DAGNET_WIDE_BF16X3"):
             split = ("bf16x3", PEAK_SPLIT_BF16X3_TFLOPS, "bf16 dense / 6 products (three bf16 terms per value; wide layers)")
+        elif split_on and "wide goal head" in info["sample_kernel"]:
+            split = ("fp16x2", PEAK_SPLIT_FP16X2_TFLOPS, "fp16 dense / 3 products (two fp16 terms per value; wide layers and step kernel)")
         elif split_on and "register-resident" in info["sample_kernel"]:
             split = ("fp16x2", PEAK_SPLIT_FP16X2_TFLOPS, "fp16 dense / 3 products (two fp16 terms per value)")
         split_bf16 = split is not None

@@ -163,7 +163,7 @@ class HipPlan:
     def info(self):
         a, b, c = C.c_int32(), C.c_int32(), C.c_int64()
         _check(load().dagnet_plan_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        kern = {3: "gemm_nt_kernel (wide goal head: batched MFMA GEMMs, bf16 x3 split products in the wide layers, + register-resident step kernel)",
+        kern = {3: "gemm_nt_kernel (wide goal head: batched MFMA GEMMs, fp16 x2 split products in the wide layers, + register-resident step kernel)",
                 2: "rollout_v2_kernel (register-resident)", 1: "dagnet_rollout_big_kernel (generic, goal buffers in global scratch)",
                 0: "dagnet_rollout_kernel (generic, LDS-tiled)"}.get(load().dagnet_plan_kernel(self._h), "none")
         return dict(tile_rows=a.value, n_tiles=b.value, lds_bytes=c.value, sample_kernel=kern)

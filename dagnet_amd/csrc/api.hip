@@ -1799,9 +1799,10 @@ static int fused_mask() {
 extern "C" int dn_gemm_set_bf16x3(int on);      // gemm_f32.hip: bit 3, split-bf16 products in the wide (N > 96) layers
 extern "C" int dagnet_op_set_fused(int32_t mask) {
     const int before = fused_mask();
-    const int now = mask < 0 ? fused_default() : (mask & 15);
+    // bit 4 (never part of the default): two fp16 terms in EVERY wide layer of dagnet_op_gemm - tests and microbenchmarks of that form
+    const int now = mask < 0 ? fused_default() : (mask & 31);
     g_fused.store(now, std::memory_order_relaxed);
-    dn_gemm_set_bf16x3((now >> 3) & 1);
+    dn_gemm_set_bf16x3(((now >> 3) & 1) ? (((now >> 4) & 1) ? 2 : 1) : 0);
     return before;
 }
 extern "C" hipError_t dn_gru_fused_fwd(int64_t M, int R, int npieces, const float *x0, int64_t ldx0, const float *x1, int64_t ldx1,

@@ -230,18 +230,35 @@ __device__ __forceinline__ i32x4 gp_rsrc(const float *base, int64_t bytes) {
 // profiles/r02_split_bf16.txt): half the error of v_mfma_f32_32x32x2_f32.  A non-finite input comes out as NaN (inf - inf
 // in the split) where the fp32 form would carry the infinity.
 // LDS: [buffer 2][term 3][row 128][16 bf16 + pad] per operand, row stride 12 dwords (16 rows x 16 B cover the 64 banks once).
+//
+// SPLIT = 2 (k-chunks of 16): two fp16 terms per value, rounded to nearest (hi = fp16(v), lo = fp16(v - hi): v_cvt_pk_f16_f32 +
+// v_fma_mixlo/hi_f16, three instructions per pair - see v2_common.h split2 for how the compiler is made to select them), THREE
+// v_mfma_f32_32x32x16_f16 per accumulator tile and chunk (lo.hi, hi.lo, hi.hi), two LDS planes per operand (48 KB: three
+// workgroups per CU).  What it gives up against the three-bf16 form: range - fp16 overflows at 65 504 and the lo term is a
+// subnormal below |v| = 0.125, so a value carries an ABSOLUTE representation error of up to 2^-25 = 3e-8 instead of fp32's
+// relative 6e-8.  Taken only where the caller says its operands are of order one or below (the goal head of the evaluation
+// path: ReLU / softmax / tanh outputs against weights of order 1 / sqrt(K)): dn_gemm_nt_gather; dn_gemm keeps three bf16 terms.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int BF3_RS = 12, BF3_PL = 128 * BF3_RS, BF3_OPB = 3 * BF3_PL;      // dwords: row, plane, operand buffer
-constexpr size_t BF3_LDS = (size_t)4 * BF3_OPB * 4;                            // bytes: two operands, two buffers
-template <int BKP, int WPC, bool BF3 = false>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+constexpr int BF3_RS = 12;      // dwords per row of a term plane
+constexpr size_t split_lds(int terms, int bm = 128) { return (size_t)2 * terms * (bm + 128) * BF3_RS * 4; }      // bytes: two operands, two buffers
+// SPLIT: 0 = fp32 MFMA, 3 = three bf16 terms / six products, 2 = two fp16 terms / three products
+// BM: rows of the workgroup tile (128, or 256 for the split forms: every wave then owns 128 x 64 - 24 KB of operands staged per
+// 2 x the MFMAs of the 128-row tile, and half the W requests and barriers per MFMA)
+template <int BKP, int WPC, int SPLIT = 0, int BM = 128>
 __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) {
-    static_assert(!BF3 || BKP == 16, "the split-bf16 form takes one 16-deep k block per chunk");
-    constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+    constexpr bool BF3 = SPLIT != 0;
+    constexpr int NPL = SPLIT ? SPLIT : 3;
+    constexpr int PLA = BM * BF3_RS, PLB = 128 * BF3_RS;           // dwords: one term plane of A / of W
+    constexpr int OPA = NPL * PLA, OPB = NPL * PLB;                // dwords: one operand buffer
+    static_assert(!BF3 || BKP == 16, "the split forms take one 16-deep k block per chunk");
+    static_assert(BF3 || BM == 128, "the fp32 form has the 128-row tile only");
+    constexpr int BN = 128, TM = BM / 64, TN = 2;
     constexpr int LDP = BKP + 4;                 // LDS row stride (floats): 16 rows x 16 B cover the 64 banks once for 36 and for 20
-    constexpr int TPR = BKP / 4, RPP = 256 / TPR, NL = 128 / RPP;      // loader: threads per row, rows per pass, passes
+    constexpr int TPR = BKP / 4, RPP = 256 / TPR, NL = 128 / RPP, NLA = BM / RPP;      // loader: threads per row, rows per pass, passes (W / A)
     extern __shared__ float smem[];
     float *sA = smem;                                             // [2][BM][LDP]
-    float *sB = smem + (BF3 ? 2 * BF3_OPB : 2 * BM * LDP);        // [2][BN][LDP]
+    float *sB = smem + (BF3 ? 2 * OPA : 2 * BM * LDP);            // [2][BN][LDP]
     unsigned *uA = reinterpret_cast<unsigned *>(sA), *uB = reinterpret_cast<unsigned *>(sB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -255,10 +272,14 @@ __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) 
     const int nk = p.K / BKP;
 
     // loader: this thread's float4 of row tid / TPR + RPP i, k columns 4 (tid % TPR) .. + 3 of a chunk
-    const int lrow = tid / TPR, lc4 = (tid % TPR) * 4;
+    // split forms: a thread writes 8 bytes per term plane at row * 12 dwords + 2 * (tid % 4), and a ds_write_b64 goes out 32 lanes at
+    // a time - eight consecutive rows put rows 0 / 5, 1 / 6, 2 / 7 on the same banks (60 = 5 * 12 wraps onto row 0: SQ_LDS_BANK_CONFLICT
+    // was a third of the LDS's active cycles); eight rows of ONE parity tile the 64 banks exactly, so lanes 0-31 take the even rows
+    // of the wave's 16 and lanes 32-63 the odd ones
+    const int lrow = BF3 ? wave * 16 + ((lane >> 2) & 7) * 2 + (lane >> 5) : tid / TPR, lc4 = (tid % TPR) * 4;
     const int lda4 = (int)p.lda * 4, ldw4 = (int)p.ldw * 4;
     const int voa = lrow * lda4 + lc4 * 4, vow = lrow * ldw4 + lc4 * 4;
-    f32x4 ga[NL], gb[NL];
+    f32x4 ga[NLA], gb[NL];
     int64_t ltile = tile;       // tile and chunk the loader is at
     int lkc = 0;
     i32x4 ra, rw;
@@ -275,7 +296,7 @@ __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) 
     auto gload = [&]() {        // request the loader's chunk, then step the loader
         const int so = lkc * (BKP * 4);
 #pragma unroll
-        for (int i = 0; i < NL; ++i) ga[i] = gp_load4(ra, voa + i * RPP * lda4, so, 0);
+        for (int i = 0; i < NLA; ++i) ga[i] = gp_load4(ra, voa + i * RPP * lda4, so, 0);
 #pragma unroll
         for (int i = 0; i < NL; ++i) gb[i] = gp_load4(rw, vow + i * RPP * ldw4, so, 0);
         if (++lkc == nk) {
@@ -284,8 +305,30 @@ __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) 
             set_desc(ltile);
         }
     };
-    // four consecutive k of one row -> 4 bf16 (8 bytes) in each of the three term planes
-    auto split_store = [&](unsigned *dst, f32x4 v) {
+    // four consecutive k of one row -> 4 bf16 / fp16 (8 bytes) in each of the term planes
+    auto split_store = [&](unsigned *dst, f32x4 v, int pl) {
+        if constexpr (SPLIT == 2) {
+            typedef float f2 __attribute__((ext_vector_type(2)));
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            float m1 = -1.0f;
+            asm volatile("" : "+s"(m1));
+            unsigned hi[2], lo[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f2 x = {v[2 * j], v[2 * j + 1]};
+                const h2 h = __builtin_convertvector(x, h2);
+                hi[j] = __builtin_bit_cast(unsigned, h);
+                h2 l;
+                _Float16 l0 = (_Float16)__builtin_fmaf((float)h[0], m1, x[0]);
+                asm("" : "+v"(l0));
+                l[0] = l0;
+                l[1] = (_Float16)__builtin_fmaf((float)h[1], m1, x[1]);
+                lo[j] = __builtin_bit_cast(unsigned, l);
+            }
+            *reinterpret_cast<uint2 *>(dst) = uint2{hi[0], hi[1]};
+            *reinterpret_cast<uint2 *>(dst + pl) = uint2{lo[0], lo[1]};
+            return;
+        }
         float e[4] = {v[0], v[1], v[2], v[3]};
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -293,7 +336,7 @@ __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) 
 #pragma unroll
             for (int k = 0; k < 4; ++k) u[k] = __builtin_bit_cast(unsigned, e[k]);
             const uint2 pk = {__builtin_amdgcn_perm(u[1], u[0], 0x07060302u), __builtin_amdgcn_perm(u[3], u[2], 0x07060302u)};
-            *reinterpret_cast<uint2 *>(dst + t * BF3_PL) = pk;
+            *reinterpret_cast<uint2 *>(dst + t * pl) = pk;
             if (t < 2) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) e[k] -= __builtin_bit_cast(float, u[k] & 0xffff0000u);
@@ -303,9 +346,9 @@ __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) 
     auto sstore = [&](int buf) {
         if constexpr (BF3) {
 #pragma unroll
-            for (int i = 0; i < NL; ++i) split_store(uA + buf * BF3_OPB + (lrow + RPP * i) * BF3_RS + (lc4 >> 1), ga[i]);
+            for (int i = 0; i < NLA; ++i) split_store(uA + buf * OPA + (lrow + RPP * i) * BF3_RS + (lc4 >> 1), ga[i], PLA);
 #pragma unroll
-            for (int i = 0; i < NL; ++i) split_store(uB + buf * BF3_OPB + (lrow + RPP * i) * BF3_RS + (lc4 >> 1), gb[i]);
+            for (int i = 0; i < NL; ++i) split_store(uB + buf * OPB + (lrow + RPP * i) * BF3_RS + (lc4 >> 1), gb[i], PLB);
         } else {
 #pragma unroll
             for (int i = 0; i < NL; ++i) *reinterpret_cast<f32x4 *>(sA + (buf * BM + lrow + RPP * i) * LDP + lc4) = ga[i];
@@ -330,18 +373,44 @@ __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) 
     int buf = 0, kc = 0;
     int m0 = (int)(tile / nbn) * BM, n0 = (int)(tile % nbn) * BN;
     while (true) {
-      if constexpr (BF3) {
+      if constexpr (SPLIT == 2) {
+        const unsigned *a_base = uA + buf * OPA + ((wm * TM) * 32 + lr) * BF3_RS + 4 * lh;
+        const unsigned *b_base = uB + buf * OPB + ((wn * TN) * 32 + lr) * BF3_RS + 4 * lh;
+        f16x8 fa[2][2], fb[2][TN];        // W fragments of the chunk, A fragments of two row tiles (the one in use, the next)
+        auto rd = [](const unsigned *q) { return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(q)); };
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            fa[0][t] = rd(a_base + t * PLA);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) fb[t][b] = rd(b_base + t * PLB + b * 32 * BF3_RS);
+        }
+        sstore(buf ^ 1);        // chunk q + 1, split on the way
+        gload();                // chunk q + 2
+        constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};      // small products first
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            if (a + 1 < TM) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) fa[(a + 1) & 1][t] = rd(a_base + t * PLA + (a + 1) * 32 * BF3_RS);
+            }
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[a & 1][PA[q]], fb[PB[q]][b], acc[a][b], 0, 0, 0);
+        }
+      } else if constexpr (BF3) {
         // this chunk's operands, in the order of their first use: 8 k of one row per lane and term
-        const unsigned *a_base = uA + buf * BF3_OPB + ((wm * TM) * 32 + lr) * BF3_RS + 4 * lh;
-        const unsigned *b_base = uB + buf * BF3_OPB + ((wn * TN) * 32 + lr) * BF3_RS + 4 * lh;
+        const unsigned *a_base = uA + buf * OPA + ((wm * TM) * 32 + lr) * BF3_RS + 4 * lh;
+        const unsigned *b_base = uB + buf * OPB + ((wn * TN) * 32 + lr) * BF3_RS + 4 * lh;
         bf16x8 fa[3][TM], fb[3][TN];
         auto rd = [](const unsigned *q) { return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4 *>(q)); };
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
 #pragma unroll
-            for (int a = 0; a < TM; ++a) fa[t][a] = rd(a_base + t * BF3_PL + a * 32 * BF3_RS);
+            for (int a = 0; a < TM; ++a) fa[t][a] = rd(a_base + t * PLA + a * 32 * BF3_RS);
 #pragma unroll
-            for (int b = 0; b < TN; ++b) fb[t][b] = rd(b_base + t * BF3_PL + b * 32 * BF3_RS);
+            for (int b = 0; b < TN; ++b) fb[t][b] = rd(b_base + t * PLB + b * 32 * BF3_RS);
         }
         sstore(buf ^ 1);        // chunk q + 1, split on the way
         gload();                // chunk q + 2
@@ -775,24 +844,53 @@ static hipError_t launch_nt_cfg(const NtArgs &a, bool veca, bool vecb, bool tran
     return hipErrorInvalidValue;
 }
 
-// split-bf16 products for the wide layers: on unless DAGNET_NO_BF16X3 is set; dn_gemm_set_bf16x3 switches at run time (tests)
+// split products for the wide layers: on unless DAGNET_NO_BF16X3 is set; dn_gemm_set_bf16x3 switches at run time (tests):
+// 0 = fp32 MFMA, 1 = three bf16 terms (two fp16 terms where the caller vouches for the operands' range), 2 = two fp16 terms in
+// every wide layer (tests and microbenchmarks of that form through dagnet_op_gemm)
 static int g_bf16x3 = -1;
 static bool bf16x3_on() {
     if (g_bf16x3 < 0) g_bf16x3 = getenv("DAGNET_NO_BF16X3") ? 0 : 1;
     return g_bf16x3 != 0;
 }
 
-static hipError_t launch_nt_pipe(const NtArgs &a, hipStream_t st) {
+#ifndef DN_H2_WPC
+#define DN_H2_WPC 3
+#endif
+static hipError_t launch_nt_pipe(const NtArgs &a, hipStream_t st, bool fp16x2_ok) {
     constexpr int BM = 128, BN = 128;
     const int64_t tiles = (int64_t)((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    static const bool no_h2 = getenv("DAGNET_WIDE_BF16X3") != nullptr;
+    if (bf16x3_on() && ((fp16x2_ok && !no_h2) || g_bf16x3 == 2)) {
+        static const int bm = getenv("DAGNET_H2_BM") ? atoi(getenv("DAGNET_H2_BM")) : 256;
+        // 256 x 128 tiles (74 KB of LDS, two workgroups per CU) where the k loop is long: 1920 -> 960 298 against 281-291 TFLOP/s at
+        // 122 880 rows; the short layers (K = 32, 64) are bound by writing C and lose with the larger tile (126 against 114 us)
+        if (bm == 256 && a.M >= 4096 && a.K >= 256) {
+            constexpr size_t LDS = split_lds(2, 256);
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_pipe_kernel<16, 2, 2, 256>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+            if (attr != hipSuccess) return attr;
+            const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.N + BN - 1) / BN);
+            const int64_t blocks = std::min<int64_t>((t256 + 7) / 8 * 8, 256 * 2);
+            hipLaunchKernelGGL((gemm_nt_pipe_kernel<16, 2, 2, 256>), dim3((unsigned)blocks), dim3(256), LDS, st, a);
+            return hipGetLastError();
+        }
+        constexpr size_t LDS = split_lds(2);          // 48 KB of LDS: three workgroups per CU
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_pipe_kernel<16, DN_H2_WPC, 2>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+        if (attr != hipSuccess) return attr;
+        const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, 256 * DN_H2_WPC);
+        hipLaunchKernelGGL((gemm_nt_pipe_kernel<16, DN_H2_WPC, 2>), dim3((unsigned)blocks), dim3(256), LDS, st, a);
+        return hipGetLastError();
+    }
     // k-chunks of 16 with three workgroups per CU (41 KB of LDS each) measured 4 % faster on the 1920 -> 960 layer than chunks
     // of 32 with two: 127.5 against 122.3 TFLOP/s at 122 880 rows (tools/ubench/gemm_bench.py)
     if (bf16x3_on()) {          // 72 KB of LDS: two workgroups per CU
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_pipe_kernel<16, 2, true>),
+        constexpr size_t BF3_LDS = split_lds(3);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_pipe_kernel<16, 2, 3>),
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)BF3_LDS);
         if (attr != hipSuccess) return attr;
         const int64_t blocks = std::min<int64_t>((tiles + 7) / 8 * 8, 256 * 2);
-        hipLaunchKernelGGL((gemm_nt_pipe_kernel<16, 2, true>), dim3((unsigned)blocks), dim3(256), BF3_LDS, st, a);
+        hipLaunchKernelGGL((gemm_nt_pipe_kernel<16, 2, 3>), dim3((unsigned)blocks), dim3(256), BF3_LDS, st, a);
         return hipGetLastError();
     }
     const size_t lds = (size_t)2 * (BM + BN) * 20 * sizeof(float);
@@ -810,9 +908,10 @@ static hipError_t launch_nt_pipe(const NtArgs &a, hipStream_t st) {
 extern "C" hipError_t dn_gemm_skinny(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
                                      int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
                                      const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st);
-extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
-                              int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
-                              const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st) {
+// fp16x2_ok: the caller vouches for operands of order one or below (see gemm_nt_pipe_kernel, SPLIT = 2)
+static hipError_t gemm_impl(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
+                            int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
+                            const int32_t *gidx, int64_t gs_g, int64_t gs_n, bool fp16x2_ok, hipStream_t st) {
     if (M <= 0 || N <= 0) return hipSuccess;
     if (act < gemm::ACT_NONE || act > gemm::ACT_RELU) return hipErrorInvalidValue;
     {   // tall-and-skinny shapes (the training step's layers): weights resident in LDS, A and C streamed by the waves themselves
@@ -830,7 +929,7 @@ extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64
         static const bool no_pipe = getenv("DAGNET_NO_PIPE") != nullptr;
         if (!no_pipe && veca && vecb && !transb && K % 16 == 0 && lda * 4 * 128 < 0x7fffffffLL && ldb * 4 * 128 < 0x7fffffffLL &&
             ldc * 4 * 128 < 0x7fffffffLL)
-            return gemm::launch_nt_pipe(a, st);
+            return gemm::launch_nt_pipe(a, st, fp16x2_ok);
         return gemm::launch_nt_cfg<2, 2, 2, 2>(a, veca, vecb, transb != 0, st);
     }
     // 128 x 96: g_dim = 90 in one column tile
@@ -839,16 +938,24 @@ extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64
     return gemm::launch_nt_cfg<4, 1, 1, 1>(a, veca, vecb, transb != 0, st);                 // 128 x 32
 }
 
+extern "C" hipError_t dn_gemm(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
+                              int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
+                              const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st) {
+    return gemm_impl(A, lda, B, ldb, transb, bias, C, ldc, M, N, K, act, slope, accumulate, gather, gidx, gs_g, gs_n, false, st);
+}
+
 extern "C" int dn_gemm_set_bf16x3(int on) {
     const int before = gemm::bf16x3_on() ? 1 : 0;
-    gemm::g_bf16x3 = on < 0 ? (getenv("DAGNET_NO_BF16X3") ? 0 : 1) : (on ? 1 : 0);
+    gemm::g_bf16x3 = on < 0 ? (getenv("DAGNET_NO_BF16X3") ? 0 : 1) : (on > 2 ? 1 : on);
     return before;
 }
 
 extern "C" hipError_t dn_gemm_nt_gather(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *C,
                                         int64_t ldc, int M, int N, int K, int act, float slope, const float *gather,
                                         const int32_t *gidx, int64_t ldg, hipStream_t st) {
-    return dn_gemm(A, lda, W, ldw, 0, bias, C, ldc, M, N, K, act, slope, 0, gather, gidx, ldg, 1, st);
+    // the goal head of the evaluation path (wide_head.hip) is this entry's only caller: ReLU / softmax / tanh outputs against
+    // weights of order 1 / sqrt(K) - the wide layers may take two fp16 terms
+    return gemm_impl(A, lda, W, ldw, 0, bias, C, ldc, M, N, K, act, slope, 0, gather, gidx, ldg, 1, true, st);
 }
 
 extern "C" hipError_t dn_gemm_nt(const float *A, int64_t lda, const float *W, int64_t ldw, const float *bias, float *C, int64_t ldc,

@@ -93,6 +93,38 @@ def test_wide_gemm_split_bf16_is_as_exact_as_fp32(M, N, K):
     assert e_bf < 1e-6, e_bf
 
 
+@pytest.mark.parametrize("M,N,K", [(3000, 960, 1920), (1111, 200, 64), (4096, 960, 32)])
+def test_wide_gemm_fp16x2_is_fp32_class_on_operands_of_order_one(M, N, K):
+    """The evaluation path's goal head multiplies its wide layers with two fp16 terms per value and three products (csrc/gemm_f32.hip,
+    SPLIT = 2; bit 4 of dagnet_op_set_fused selects that form for dagnet_op_gemm).  Its contract is operands of order one or
+    below: softmax rows (1 / g_dim), tanh / ReLU outputs, weights of order 1 / sqrt(K).  On such operands the result against fp64
+    must be in the fp32 MFMA's class relative to sum |a||w|, and within 1e-7 of the output's scale in absolute terms."""
+    g = torch.Generator().manual_seed(N + K + 1)
+    A = torch.randn((M, K), generator=g)
+    A[:, : K // 2] = torch.softmax(4 * A[:, : K // 2], dim=1)          # a block of small positive values, like the goal distribution
+    A[:, K // 2:] = torch.tanh(A[:, K // 2:])
+    A = A.to(DEV)
+    W = (torch.randn((N, K), generator=g) / K ** 0.5).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    ref = A.double() @ W.double().t() + bias.double()
+    scale = (A.double().abs() @ W.double().abs().t() + bias.double().abs()).clamp_min(1e-30)
+    out = {}
+    before = _ops.set_fused(-1)
+    try:
+        for mask in (31, 15, 7):
+            _ops.set_fused(mask)
+            C = torch.empty((M, N), device=DEV)
+            _ops.gemm(A, W, C, bias=bias)
+            out[mask] = C
+    finally:
+        _ops.set_fused(before)
+    assert not torch.equal(out[31], out[15]), "bit 4 did not change the products"
+    err = {m: float(((v.double() - ref).abs() / scale).max()) for m, v in out.items()}
+    print(f"\nK = {K}: max error / sum|a||w|: fp16x2 {err[31]:.2e}, bf16x3 {err[15]:.2e}, fp32 MFMA {err[7]:.2e}")
+    assert err[31] <= max(3 * err[7], 3e-7), err
+    assert float((out[31].double() - ref).abs().max()) < 1e-6 * float(ref.abs().max()), err
+
+
 @pytest.mark.parametrize("M,N,K", [(40960, 64, 64), (5001, 192, 64), (2049, 32, 64), (3000, 64, 32), (7001, 90, 90), (4100, 90, 64),
                                    (2500, 90, 32), (2100, 32, 90), (3333, 64, 20), (2048, 2, 64), (2300, 64, 2), (100, 64, 64), (31, 50, 64),
                                    (3000, 33, 64), (2600, 64, 130), (2200, 128, 64), (1, 64, 64), (2500, 160, 64), (9000, 96, 96)])

@@ -10,6 +10,10 @@ from dagnet_amd import _ops  # noqa: E402
 
 M = int(sys.argv[1]) if len(sys.argv) > 1 else 61440
 dev = "cuda:0"
+# DAGNET_FUSED_MASK: 7 = fp32 MFMA, 15 = three bf16 terms in the wide layers (default), 31 = two fp16 terms
+if "DAGNET_FUSED_MASK" in os.environ:
+    _ops.set_fused(int(os.environ["DAGNET_FUSED_MASK"]))
+    print("fused mask", os.environ["DAGNET_FUSED_MASK"])
 
 
 def bench(fn, reps=3, n=4):
@@ -27,7 +31,10 @@ def bench(fn, reps=3, n=4):
     return best
 
 
-for (N, K, act) in ((960, 1920, 0), (960, 960, 0), (960, 64, 0), (960, 32, 2), (40, 960, 0)):
+SHAPES = ((960, 1920, 0), (960, 960, 0), (960, 64, 0), (960, 32, 2), (40, 960, 0))
+if "GEMM_ONLY" in os.environ:          # one shape, by its K (counter passes)
+    SHAPES = tuple(sh for sh in SHAPES if sh[1] == int(os.environ["GEMM_ONLY"]) and sh[0] == 960)
+for (N, K, act) in SHAPES:
     A = torch.randn((M, K), device=dev)
     W = torch.randn((N, K), device=dev) / K ** 0.5
     b = torch.randn(N, device=dev)

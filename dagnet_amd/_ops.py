@@ -146,9 +146,9 @@ def _rows(t: torch.Tensor) -> torch.Tensor:
 
 
 def set_fused(mask: int) -> int:
-    """Select the fused kernels (bit 0 GRU layer forward, 1 dense blocks forward, 2 dense blocks backward, 3 split-bf16 products in
-    the wide GEMM and in the register-resident rollout kernels; < 0: default).
-    -> the previous mask."""
+    """Select the fused kernels (bit 0 GRU layer forward, 1 dense blocks forward, 2 dense blocks backward, 3 split products on the
+    16-bit matrix pipe in the wide GEMM layers and in the register-resident rollout kernels, 4 two fp16 terms instead of three
+    bf16 ones in dagnet_op_gemm's wide layers - tests only; < 0: default = bits 0-3).  -> the previous mask."""
     return int(_lib().dagnet_op_set_fused(int(mask)))
 
 

@@ -262,10 +262,13 @@ int dagnet_op_linear_pieces_bwd(int64_t M, const float *dy, int64_t lddy, const 
 /* Selects the fused training kernels at run time: bit 0 = dagnet_op_gru_layer_fwd's one-kernel form, bit 1 = dagnet_op_mlp_chain_fwd's,
  * bit 2 = dagnet_op_mlp2_bwd's (a cleared bit makes the entry point take its layer-by-layer form / return 1); bit 3 = split
  * products on the 16-bit matrix pipe, fp32 in / out / accumulation, fp32-MFMA-class error: three bf16 terms per value and six
- * products in the wide layers (more than 96 outputs) of dagnet_op_gemm and of the g_dim = 960 goal head; two fp16 terms per value
- * and three products in every dense and graph product of the register-resident rollout kernels behind dagnet_sample
- * (csrc/rollout_v2.hip; a model with a weight beyond fp16's range keeps the fp32-MFMA kernels, which are also what a cleared
- * bit selects); mask < 0 restores the default (all on, minus
+ * products in the wide layers (more than 96 outputs) of dagnet_op_gemm; two fp16 terms per value and three products in the wide
+ * layers of the g_dim = 960 goal head behind dagnet_sample / dagnet_forward (operands of order one or below by construction;
+ * DAGNET_WIDE_BF16X3 in the environment keeps three bf16 terms there) and in every dense and graph product of the
+ * register-resident rollout kernels behind dagnet_sample (csrc/rollout_v2.hip; a model with a weight beyond fp16's range keeps
+ * the fp32-MFMA kernels, which are also what a cleared bit selects); bit 4 (never on by default; needs bit 3) = two fp16 terms
+ * in dagnet_op_gemm's wide layers too - fp16 overflows at 65 504 and carries an absolute representation error of up to 3e-8 per
+ * operand value below 0.125, so this is for tests and microbenchmarks of that form; mask < 0 restores the default (bits 0-3 on, minus
  * DAGNET_NO_GRU_FUSED / DAGNET_NO_MLP_FUSED / DAGNET_NO_MLP_BWD_FUSED / DAGNET_NO_BF16X3).  -> the previous mask.
  * No counterpart in the reference: a switch for A/B comparisons and tests. */
 int dagnet_op_set_fused(int32_t mask);

@@ -88,6 +88,9 @@ WORKLOADS = {
     # configs[4], training leg (row T): one optimizer step of DAG-Net on a chunk of scenes, full 50-step sequence
     "train_dagnet_bsk_1024": dict(kind="dagnet", scenes=1024, agents=10, K=1, obs=10, pred=40, args=dict(n_layers=2), train=True),
     "train_dagnet_bsk_8192": dict(kind="dagnet", scenes=8192, agents=10, K=1, obs=10, pred=40, args=dict(n_layers=2), train=True),
+    # the same step at the SDD shape (models/dagnet/train_sdd.py:29-30,334): g_dim = 960, ragged scenes, obs 8 / pred 12
+    "train_dagnet_sdd_4096": dict(kind="dagnet", scenes=4096, agents=0, K=1, obs=8, pred=12, args=dict(n_layers=2, g_dim=960),
+                                  data="sdd", g_cells=(32, 30), train=True),
 }
 
 
@@ -220,10 +223,12 @@ def bench_train(opt, wl, rank, world, dev, dist):
     S, T = wl["scenes"], wl["obs"] + wl["pred"]
     sizes = scene_sizes(wl, seed=rank)
     n_rows = int(sum(sizes))
-    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = [t.to(dev) for t in syn.make_batch(sizes, wl["obs"], wl["pred"], 1000 + rank)]
+    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = [t.to(dev) for t in syn.make_batch(sizes, wl["obs"], wl["pred"], 1000 + rank,
+                                                                                            kind=wl.get("data", "bsk"),
+                                                                                            g_cells=wl.get("g_cells", (9, 10)))]
     traj, rel = torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0)
     goals = torch.cat((obs_goals, gt_goals), 0).to(torch.int32)
-    from dagnet_amd.adjacency_matrix import BlockDiagAdj
+    n_params = sum(p.numel() for p in model.parameters())
     adj = compute_adjs_distsim(a, sse, obs, gt, compact=True)
     optim = _ops.ClipAdam(list(model.parameters()), lr=1e-3, clip=10.0)
     training.attach_grad_arena(model, optim)
@@ -272,7 +277,7 @@ def bench_train(opt, wl, rank, world, dev, dist):
         dt = float(tmax.item())
     if rank != 0:
         return
-    flop = train_flops_per_row_step(a, wl["agents"], 2 * wl["agents"]) * n_rows * (T - 1)
+    flop = train_flops_per_row_step(a, wl["agents"] or n_rows / S, model.d_dim) * n_rows * (T - 1)
     achieved = flop / (dt / opt.steps) / 1e12
     # HBM-side bytes of one optimizer step, summed over all its kernels, from the newest committed counter passes of this workload
     # (tools/train_pmc.sh -> profiles/*_pmc.json); the tape the backward pass cannot avoid is ~150 GB at this size
@@ -286,14 +291,16 @@ def bench_train(opt, wl, rank, world, dev, dist):
             continue
     hbm = None if traffic is None else traffic / (dt / opt.steps) / 1e9
     line = {
-        "metric": "training trajectories/sec (one optimizer step, teacher-forced 50-step sequences)",
+        "metric": f"training trajectories/sec (one optimizer step, teacher-forced {T}-step sequences)",
         "value": n_rows * world * opt.steps / dt, "unit": "trajectories/s", "n_gpus": world, "steps": opt.steps, "warmup": opt.warmup,
-        "ms_per_step": dt / opt.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "ms_per_step": dt / opt.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        # layers with more than 96 outputs (g_dim = 960 only) multiply as three bf16 terms / six products (dagnet_op_gemm)
+        "dtype": "f32 (bf16x3 products in the wide layers)" if a.g_dim > 96 and (_ops.set_fused(-1) & 8) else "f32",
         "data": "synthetic",
-        "config": {"workload": opt.workload, "model": "dagnet", "scenes_per_gpu": S, "agents_per_scene": wl["agents"], "seq_len": T,
+        "config": {"workload": opt.workload, "model": "dagnet", "scenes_per_gpu": S, "agents_per_scene": wl["agents"] or n_rows / S, "seq_len": T,
                    "rows_per_gpu": n_rows, "batchnorm": "synchronised over all ranks" if opt.sync_bn else "per-rank statistics",
                    "hip_graph": not opt.no_graph,
-                   "parallelism": f"scenes sharded x{world}, one all-reduce of 184 350 fp32 gradients per step"},
+                   "parallelism": f"scenes sharded x{world}, one all-reduce of {format(n_params, ',').replace(',', ' ')} fp32 gradients per step"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MATRIX_TFLOPS, "traffic": traffic,
                      "hbm": None if hbm is None else {"achieved": hbm, "peak": 8000.0, "unit": "GB/s", "frac": hbm / 8000.0,
@@ -310,13 +317,14 @@ def cpu_train_baseline(wl):
     """The oracle's training step (torch CPU autograd over the dense-graph restatement) on 32 scenes."""
     from oracle import dagnet_oracle as orc
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    scenes, n = 32, wl["agents"]
+    scenes, n = 32, wl["agents"] or 6
     a = syn.make_args(obs_len=wl["obs"], pred_len=wl["pred"], **wl["args"])
     sd = syn.random_state_dict(dagnet_amd.DAGNet(a, n), 128)
     cfg = orc.make_cfg(n_max_agents=n, **{k: getattr(a, k) for k in ("x_dim", "h_dim", "z_dim", "rnn_dim", "n_layers", "g_dim", "graph_model",
                                                                         "graph_hid", "adjacency_type", "top_k_neigh", "sigma", "alpha",
                                                                         "n_heads")})
-    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = syn.make_batch([n] * scenes, wl["obs"], wl["pred"], 1)
+    obs, gt, obs_rel, gt_rel, obs_goals, gt_goals, sse = syn.make_batch([n] * scenes, wl["obs"], wl["pred"], 1, kind=wl.get("data", "bsk"),
+                                                                        g_cells=wl.get("g_cells", (9, 10)))
     traj, rel = torch.cat((obs, gt), 0), torch.cat((obs_rel, gt_rel), 0)
     goals = orc.one_hot(torch.cat((obs_goals, gt_goals), 0).long(), a.g_dim)
     adj = orc.adjacency_seq(cfg, sse, traj)

@@ -1419,21 +1419,40 @@ def bn_train(bn: torch.nn.BatchNorm1d, x: torch.Tensor, tanh_out: bool) -> torch
     return y
 
 
+GAT_WIDE_OUT = 128      # out heads wider than this aggregate BEFORE their dense layer (gat_train)
+
+
 def gat_stacks(gat):
     """The stacked weights of a GAT: all heads' W as one [in, P*F] matrix, their attention vectors as [P, 2F], the out head's
-    as [1, 2*nout].  Built once per training step, outside the time loop."""
-    return (stack(False, *[att.W for att in gat.attentions]), stack(True, *[att.a for att in gat.attentions]),
-            stack(True, gat.out_att.a))
+    as [1, 2*nout] - and, for a wide out head (g_dim in the hundreds), its attention vectors folded through its weights:
+    [1, 2*P*F] = [W a_src | W a_dst].  Built once per training step, outside the time loop."""
+    Wcat, acat = stack(False, *[att.W for att in gat.attentions]), stack(True, *[att.a for att in gat.attentions])
+    a2 = stack(True, gat.out_att.a)
+    fold = None
+    if gat.nout > GAT_WIDE_OUT:
+        # (x W) . a = x . (W a): [2, nout] x W[P*F, nout]^T -> [2, P*F]; differentiable in W and in a (LinearFn: y = x W^T)
+        f2 = LinearFn.apply(gat.out_att.W, None, ACT_NONE, 0.0, (0,), None, 0, 0, a2.view(2, gat.nout))
+        fold = stack(True, f2)
+    return Wcat, acat, a2, fold
 
 
 def gat_train(gat, x, adj, plan, stacks=None):
-    """GAT.forward in train mode (gat_model.py:18-22): P heads -> concat -> out head -> BatchNorm (batch statistics) -> tanh."""
+    """GAT.forward in train mode (gat_model.py:18-22): P heads -> concat -> out head -> BatchNorm (batch statistics) -> tanh.
+    A wide out head (nout > GAT_WIDE_OUT: the g_dim = 960 goal graph of the SDD models, models/dagnet/train_sdd.py:334) runs in
+    the order of the evaluation path's goal head (csrc/wide_head.hip): its logits from the folded vectors, (x2 W) . a = x2 . (W a),
+    and its aggregation on the P*F-wide head outputs BEFORE the dense layer, alpha (x2 W) = (alpha x2) W - the attention kernel
+    then works on P*F = 32 columns per row instead of nout (whose scene tile would not fit the LDS), and the nout-wide matrix
+    is written once."""
     P, F = gat.nheads, gat.nhid
-    Wcat, acat, a2 = stacks if stacks is not None else gat_stacks(gat)
+    Wcat, acat, a2, fold = stacks if stacks is not None else gat_stacks(gat)
     Wh = MatmulFn.apply(x, Wcat)
     x2 = GatAttnFn.apply(Wh, acat, adj, plan, P, F, float(gat.alpha), True)
-    Wh2 = MatmulFn.apply(x2, gat.out_att.W)
-    o = GatAttnFn.apply(Wh2, a2, adj, plan, 1, gat.nout, float(gat.alpha), False)
+    if fold is not None:
+        x3 = GatAttnFn.apply(x2, fold, adj, plan, 1, P * F, float(gat.alpha), False)
+        o = MatmulFn.apply(x3, gat.out_att.W)
+    else:
+        Wh2 = MatmulFn.apply(x2, gat.out_att.W)
+        o = GatAttnFn.apply(Wh2, a2, adj, plan, 1, gat.nout, float(gat.alpha), False)
     return bn_train(gat.bn1, o, True)
 
 

@@ -160,7 +160,7 @@ def build_case(name, kind, args_kw, sizes, obs_len, pred_len, seed, K, data_kind
 
 
 def train_case(name, kind, args_kw, sizes, obs_len, pred_len, seed, kld_weight=0.5, ce_weight=1e-2, lr=1e-3, clip=10.0,
-               data_kind="bsk", g_cells=(9, 10)):
+               data_kind="bsk", g_cells=(9, 10), thin=False):
     """One training step exactly as the reference issues it (models/dagnet/train_bsk.py:259-291 and the avrnn /
     baseline analogues): model.train(), forward on the full sequence (DAG-Net) or the observed steps (others),
     loss = w_kld KLD + NLL (+ CE_weight CE), backward, clip_grad_norm_(params, clip), Adam step.
@@ -207,6 +207,11 @@ def train_case(name, kind, args_kw, sizes, obs_len, pred_len, seed, kld_weight=0
                 data_kind=data_kind, g_cells=list(g_cells), n_max_agents=n_max, kld_weight=kld_weight, ce_weight=ce_weight, lr=lr,
                 clip=clip, checks=dict(obs=checksum(obs), eps=checksum(eps),
                                        weights=float(sum(checksum(v) for v in sd.values() if v.dtype.is_floating_point))))
+    if thin:        # a model with millions of parameters: of every large tensor keep each 61st element and the L2 norm
+        for k_ in [k_ for k_, v in out.items() if isinstance(v, np.ndarray) and v.size > 65536]:
+            v = out.pop(k_)
+            out[k_ + "@thin"] = v.reshape(-1)[::61].copy()
+            out[k_ + "@norm"] = np.float64(np.sqrt((v.astype(np.float64) ** 2).sum()))
     out["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(f"{name}: N={N} T={T} kld={float(kld):.5f} nll={float(nll):.5f} ce={float(ce):.5f} |g|={float(total_norm):.4f}")
@@ -277,6 +282,13 @@ def train_cases():
     train_case("train_dagnet_tiny_gcn", "dagnet", dict(TINY, n_layers=1, graph_model="gcn", adjacency_type=0), [2, 5, 3], 4, 5, 64,
                g_cells=(3, 4), data_kind="sdd")
     train_case("train_dagnet_bsk_gat_n5", "dagnet", dict(REAL, n_layers=2), [5, 5, 5], 3, 4, 65)
+    train_sdd_case()
+
+
+def train_sdd_case():
+    # --- one training step at the SDD shape: g_dim = 32 x 30 = 960, ragged scenes (models/dagnet/train_sdd.py:29-30,334)
+    train_case("train_dagnet_sdd_g960", "dagnet", dict(REAL, g_dim=960, n_layers=2), [2, 7, 4], 3, 4, 66, data_kind="sdd", g_cells=(32, 30),
+               thin=True)
 
 
 def data_case():
@@ -517,6 +529,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "train":
         return train_cases()
+    if len(sys.argv) > 1 and sys.argv[1] == "train_sdd":
+        return train_sdd_case()
     if len(sys.argv) > 1 and sys.argv[1] == "layers":
         return layer_case()
     if len(sys.argv) > 1 and sys.argv[1] == "train3":

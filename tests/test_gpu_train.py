@@ -65,7 +65,7 @@ def test_train_step_matches_reference(name):
     check_step(out, gold, meta["lr"], meta["clip"])
 
 
-@pytest.mark.parametrize("name", ["train_dagnet_tiny_gat", "train_dagnet_tiny_gcn", "train_vrnn_tiny"])
+@pytest.mark.parametrize("name", ["train_dagnet_tiny_gat", "train_dagnet_tiny_gcn", "train_vrnn_tiny", "train_dagnet_sdd_g960"])
 def test_train_step_with_gradient_arena(name):
     """Flat gradient buffer + in-place accumulation by the backward kernels: same step as the plain autograd path."""
     meta, gold = cases.load_golden(name)

@@ -222,6 +222,7 @@ class StepPool:
         """Sites reserved before the first next_t() are per-step (one slot): stacked weights, loop invariants."""
         self.T, self.t, self.n_site, self.active, self.device = int(T), -1, 0, True, torch.device(device)
         self.gen += 1
+        self.bn_calls = {}
         BR.keep.clear()
 
     def next_t(self, t):
@@ -229,6 +230,9 @@ class StepPool:
 
     def end(self):
         self.active = False
+        for bn, n in getattr(self, "bn_calls", {}).items():     # nn.BatchNorm1d counts its train-mode calls
+            bn.num_batches_tracked += n
+        self.bn_calls = {}
 
     def site(self):
         """Reserve the next site of the current time step -> slot (site, t), or None when the pool is not active."""
@@ -1253,6 +1257,7 @@ class BnFn(torch.autograd.Function):
                                        _p(run_mean), _p(run_var), _p(tmp), _p(ws), _stream(x.device)))
         ctx.save_for_backward(x, gamma, stat, y)
         ctx.tanh_out = tanh_out
+        ctx.gamma_param, ctx.beta_param = gamma, beta
         return y
 
     @staticmethod
@@ -1261,12 +1266,18 @@ class BnFn(torch.autograd.Function):
         M, N = x.shape
         dy = _rows(dy)
         dx = POOL.at(ctx.slot, "dx", (M, N), x)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        # gradient sinks (training.attach_grad_arena): the reduction's second stage adds into p.grad, autograd gets None - one
+        # AccumulateGrad add per parameter and call less (4 per time step of the DAG-Net step)
+        gsink, bsink = _sink(ctx.gamma_param), _sink(ctx.beta_param)
+        acc = gsink is not None and bsink is not None
+        dgamma, dbeta = (gsink, bsink) if acc else (torch.empty_like(gamma), torch.empty_like(gamma))
         sums = POOL.at(ctx.slot, "sums", (2 * N,), x)
         ws = _ws(x.device, _lib().dagnet_op_col_workspace(M, N))
         (xp, ldx), (gp, ldg), (yp, ldy), (dp, ldd) = _m(x), _m(dy), _m(y), _m(dx)
         _check(_lib().dagnet_op_bn_bwd(M, N, xp, ldx, _p(stat), _p(gamma), gp, ldg, yp, ldy, int(ctx.tanh_out), dp, ldd, _p(dgamma),
-                                       _p(dbeta), 0, _p(sums), _p(ws), _stream(x.device)))
+                                       _p(dbeta), int(acc), _p(sums), _p(ws), _stream(x.device)))
+        if acc:
+            return dx, None, None, None, None, None, None, None
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
@@ -1415,7 +1426,10 @@ def bn_train(bn: torch.nn.BatchNorm1d, x: torch.Tensor, tanh_out: bool) -> torch
     fn = SyncBnFn if BN_SYNC.mode is not None else BnFn
     y = fn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, momentum, tanh_out)
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked += 1
+        if POOL.active:             # inside a training step: one add per module at the end of the pass (StepPool.end), not one per call
+            POOL.bn_calls[bn] = POOL.bn_calls.get(bn, 0) + 1
+        else:
+            bn.num_batches_tracked += 1
     return y
 
 
@@ -1550,12 +1564,28 @@ class ClipAdam:
                     p.grad = p.grad.contiguous()
                 _check(lib.dagnet_op_sumsq(p.grad.numel(), _p(p.grad), _p(self.sumsq), st))
         self.step_count += 1
+        flat = getattr(self, "flat", None)
+        if flat is not None and arena is not None and len(live) == len(self.params) and self._flat_ok(flat, arena):
+            # parameters, gradients and moments are views of four flat buffers in one layout (training.attach_grad_arena): one launch
+            _check(lib.dagnet_op_adam(arena.numel(), _p(flat["p"]), _p(arena), _p(flat["m"]), _p(flat["v"]), _p(self.sumsq),
+                                      float(self.clip or 0.0), self.lr, self.betas[0], self.betas[1], self.eps, self.step_count, st))
+            for p in self.params:
+                torch.autograd.graph.increment_version(p)
+            return
         for p, m, v in live:
             _check(lib.dagnet_op_adam(p.numel(), _p(p.data), _p(p.grad), _p(m), _p(v), _p(self.sumsq), float(self.clip or 0.0), self.lr,
                                       self.betas[0], self.betas[1], self.eps, self.step_count, st))
             # the kernel wrote through the raw pointer: tell autograd, and the modules' packed-weight cache
             # (_runtime.HipBacked._fingerprint keys on the version counters), that the parameter changed
             torch.autograd.graph.increment_version(p)
+
+    def _flat_ok(self, flat, arena):
+        """Every parameter, gradient and moment still IS its slice of the flat buffers (something may have re-allocated one)."""
+        bp, bg, bm, bv = flat["p"].data_ptr(), arena.data_ptr(), flat["m"].data_ptr(), flat["v"].data_ptr()
+        for p, m, v, o in zip(self.params, self.m, self.v, flat["offs"]):
+            if p.data_ptr() != bp + 4 * o or p.grad.data_ptr() != bg + 4 * o or m.data_ptr() != bm + 4 * o or v.data_ptr() != bv + 4 * o:
+                return False
+        return True
 
     def total_norm(self) -> torch.Tensor:
         return self.sumsq.sqrt().float()

@@ -35,25 +35,49 @@ def table_plan(scene_ptr, device) -> _capi.HipPlan:
     return plan
 
 
-def attach_grad_arena(model, optimizer=None) -> torch.Tensor:
+def attach_grad_arena(model, optimizer=None, flat_params=None) -> torch.Tensor:
     """Give every parameter's .grad a view of ONE flat fp32 buffer (zeroed) and mark the parameters as gradient sinks: the
     weight / bias gradient kernels of _ops then accumulate in place over the time steps instead of returning fresh tensors
     for autograd to add up, and the data-parallel all-reduce is one call on the flat buffer.  Plain autograd semantics
     otherwise (gradients accumulate over backward() calls until zeroed); torch.autograd.grad(loss, params) is not
-    supported for sink parameters (they report None)."""
+    supported for sink parameters (they report None).
+
+    flat_params (default: when ``optimizer`` is an _ops.ClipAdam): the parameters' storage and the optimizer's moments become
+    views of flat buffers in the SAME layout (every tensor starts at a multiple of 64 floats, so the kernels' 16-byte paths stay
+    available; the gaps hold zeros), and clip + Adam over the whole model is ONE launch instead of one per parameter
+    (_ops.ClipAdam.step).  The parameters stay nn.Parameters of their modules; whatever re-allocates one later (module.to(), a
+    GRU's flatten_parameters) only sends the optimizer back to its per-tensor launches."""
     params = [p for p in model.parameters() if p.requires_grad]
-    arena = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=params[0].device)
-    defer = _ops.DeferredGrads()              # partial sums over the time steps, one reduction per backward pass
-    off = 0
+    if flat_params is None:
+        flat_params = isinstance(optimizer, _ops.ClipAdam) and [id(p) for p in optimizer.params] == [id(p) for p in params]
+    align = 64 if flat_params else 1
+    offs, off = [], 0
     for p in params:
-        n = p.numel()
-        p.grad = arena[off:off + n].view_as(p)
+        offs.append(off)
+        off += (p.numel() + align - 1) // align * align
+    total = off if flat_params else sum(p.numel() for p in params)
+    dev = params[0].device
+    arena = torch.zeros(total, dtype=torch.float32, device=dev)
+    defer = _ops.DeferredGrads()              # partial sums over the time steps, one reduction per backward pass
+    for p, o in zip(params, offs):
+        p.grad = arena[o:o + p.numel()].view_as(p)
         p._hip_sink = True
         p._hip_defer = defer
-        off += n
     model._hip_grad_arena = arena
     if optimizer is not None:
         optimizer.arena = arena
+    if flat_params:
+        fp, fm, fv = (torch.zeros(total, dtype=torch.float32, device=dev) for _ in range(3))
+        with torch.no_grad():
+            for i, (p, o) in enumerate(zip(params, offs)):
+                n = p.numel()
+                fp[o:o + n].copy_(p.detach().reshape(-1))
+                fm[o:o + n].copy_(optimizer.m[i].reshape(-1))
+                fv[o:o + n].copy_(optimizer.v[i].reshape(-1))
+                p.data = fp[o:o + n].view_as(p)
+                optimizer.m[i] = fm[o:o + n].view_as(p)
+                optimizer.v[i] = fv[o:o + n].view_as(p)
+        optimizer.flat = dict(p=fp, m=fm, v=fv, offs=offs)
     return arena
 
 

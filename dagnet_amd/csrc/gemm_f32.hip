@@ -220,6 +220,17 @@ __device__ __forceinline__ i32x4 gp_rsrc(const float *base, int64_t bytes) {
                  0x00020000};
 }
 
+// tanh on the hardware exp2 / rcp: (1 - e) / (1 + e) with e = exp(-2|v|) from 0.1 up (absolute error ~1e-7 = relative below 1e-6
+// there), the odd series v (1 - v^2/3 + 2 v^4/15) below (truncation 5e-8 relative at 0.1) - the plain 1 - 2 / (1 + exp(2v)) form of
+// round 2 cancelled near zero (relative error 1e-3 at |v| = 1e-4, where the other epilogues' tanhf is exact: ADVICE r2)
+__device__ __forceinline__ float tanh_hw(float v) {
+    const float a = fabsf(v), v2 = v * v;
+    const float e = __builtin_amdgcn_exp2f(a * -2.8853900817779268f);
+    const float big = (1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e);
+    const float small = v * fmaf(v2, fmaf(v2, 0.13333334f, -0.33333334f), 1.0f);
+    return a < 0.1f ? small : copysignf(big, v);
+}
+
 // BKP: k-chunk (32 or 16), WPC: workgroups per CU the registers are budgeted for (LDS: 2 * 256 * (BKP + 4) * 4 bytes each)
 //
 // BF3 (k-chunks of 16): the same products on the bf16 matrix pipe.  Both operands are split where they are staged into LDS, each
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) 
                             if (p.act == ACT_LRELU) v = fmaxf(v, v * p.slope);
                             else if (p.act == ACT_RELU) v = fmaxf(v, 0.f);
                             else if (p.act == ACT_TANH)
-                                v = 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * 2.8853900817779268f));
+                                v = tanh_hw(v);
                             gp_store1(v, rc, vo + ((r & 3) + 8 * (r >> 2)) * ldc4, 0, 0);
                             acc[a][b][r] = 0.f;
                         }

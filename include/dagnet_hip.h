@@ -125,8 +125,9 @@ int dagnet_sample(const dagnet_model *m, const dagnet_plan *p, int32_t T,
  *              step for KLD/NLL, sum for CE)
  *   d_h_out    [L,N,R]
  * A NaN in d_traj_rel / d_traj makes the three losses NaN, and d_h_out NaN for the row (VRNN) or the batch (graph models).
- * The losses are summed in buffers of the plan: a call is refused (DAGNET_ERR_INVALID) while an earlier call on this plan is
- * still running on another stream - use one plan per stream; calls on one stream are ordered.            */
+ * The losses are summed in buffers of the plan: a call that arrives on another stream than the previous call on this plan is
+ * ordered behind it on the device (it waits for that call's completion event), so calls on one plan never overlap - use one
+ * plan per stream where they should.  Streams under graph capture are not tracked.            */
 int dagnet_forward(const dagnet_model *m, const dagnet_plan *p, int32_t T,
                    const float *d_traj, const float *d_traj_rel, const int32_t *d_goals,
                    const float *d_adj, int64_t adj_dense_ld, const float *d_eps, uint64_t seed,

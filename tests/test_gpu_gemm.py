@@ -93,6 +93,35 @@ def test_wide_gemm_split_bf16_is_as_exact_as_fp32(M, N, K):
     assert e_bf < 1e-6, e_bf
 
 
+def test_pipelined_epilogue_tanh_keeps_small_values():
+    """The pipelined wide kernel's epilogue computes tanh on the hardware exp2 / rcp.  Near zero that must not cancel: outputs
+    of 1e-5 .. 1e-2 keep a relative error of fp32 rounding, like tanhf in the other kernels' epilogues."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 2048, 256, 64
+    A = torch.randn((M, K), generator=g).to(DEV)
+    scale = torch.logspace(-5, 0, N).to(DEV)                       # column n of the product is of order scale[n]
+    W = (torch.randn((N, K), generator=g).to(DEV) / K ** 0.5) * scale[:, None]
+    C = torch.empty((M, N), device=DEV)
+    before = _ops.set_fused(7)                                     # fp32 products: what is tested is the epilogue
+    try:
+        _ops.gemm(A, W, C, act=_ops.ACT_TANH)
+    finally:
+        _ops.set_fused(before)
+    pre = A.double() @ W.double().t()
+    want = torch.tanh(pre)
+    # the product itself carries an absolute error of ~1e-7 x scale: compare tanh of the kernel's own pre-activation
+    C0 = torch.empty((M, N), device=DEV)
+    before = _ops.set_fused(7)
+    try:
+        _ops.gemm(A, W, C0)
+    finally:
+        _ops.set_fused(before)
+    rel = ((C.double() - torch.tanh(C0.double())).abs() / torch.tanh(C0.double()).abs().clamp_min(1e-30))
+    big = C0.abs() > 1e-6
+    assert float(rel[big].max()) < 5e-6, float(rel[big].max())
+    assert float((C.double() - want).abs().max()) < 1e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(3000, 960, 1920), (1111, 200, 64), (4096, 960, 32)])
 def test_wide_gemm_fp16x2_is_fp32_class_on_operands_of_order_one(M, N, K):
     """The evaluation path's goal head multiplies its wide layers with two fp16 terms per value and three products (csrc/gemm_f32.hip,

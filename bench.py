@@ -88,6 +88,9 @@ WORKLOADS = {
     # configs[4], training leg (row T): one optimizer step of DAG-Net on a chunk of scenes, full 50-step sequence
     "train_dagnet_bsk_1024": dict(kind="dagnet", scenes=1024, agents=10, K=1, obs=10, pred=40, args=dict(n_layers=2), train=True),
     "train_dagnet_bsk_8192": dict(kind="dagnet", scenes=8192, agents=10, K=1, obs=10, pred=40, args=dict(n_layers=2), train=True),
+    # twice the rows per optimizer step: the step's kernels are latency-bound chains, larger ones amortise better (823 k against
+    # 715 k training trajectories/s); 32768 scenes no longer fit the 288 GB (the stacked tape of 16384 takes about half of it)
+    "train_dagnet_bsk_16384": dict(kind="dagnet", scenes=16384, agents=10, K=1, obs=10, pred=40, args=dict(n_layers=2), train=True),
     # the same step at the SDD shape (models/dagnet/train_sdd.py:29-30,334): g_dim = 960, ragged scenes, obs 8 / pred 12
     "train_dagnet_sdd_4096": dict(kind="dagnet", scenes=4096, agents=0, K=1, obs=8, pred=12, args=dict(n_layers=2, g_dim=960),
                                   data="sdd", g_cells=(32, 30), train=True),
@@ -306,7 +309,7 @@ def bench_train(opt, wl, rank, world, dev, dist):
                      "hbm": None if hbm is None else {"achieved": hbm, "peak": 8000.0, "unit": "GB/s", "frac": hbm / 8000.0,
                                                       "note": "all kernels of the step: (2 x FETCH_SIZE + WRITE_SIZE) / step time"},
                      "kernel": "layer-by-layer operators (gemm_f32.hip + train_ops.hip): bound by streaming activations, see DESIGN.md 4.5"},
-        "loss": float(loss.detach()),
+        "loss": float(loss.detach()), "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(dev) / 1e9,
     }
     if not opt.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_train_baseline(wl)

@@ -252,27 +252,30 @@ __device__ __forceinline__ float tanh_hw(float v) {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 constexpr int BF3_RS = 12;      // dwords per row of a term plane
-constexpr size_t split_lds(int terms, int bm = 128) { return (size_t)2 * terms * (bm + 128) * BF3_RS * 4; }      // bytes: two operands, two buffers
+constexpr size_t split_lds(int terms, int bm = 128, int bn = 128) { return (size_t)2 * terms * (bm + bn) * BF3_RS * 4; }      // bytes: two operands, two buffers
 // SPLIT: 0 = fp32 MFMA, 3 = three bf16 terms / six products, 2 = two fp16 terms / three products
 // BM: rows of the workgroup tile (128, or 256 for the split forms: every wave then owns 128 x 64 - 24 KB of operands staged per
 // 2 x the MFMAs of the 128-row tile, and half the W requests and barriers per MFMA)
-template <int BKP, int WPC, int SPLIT = 0, int BM = 128>
-__global__ __launch_bounds__(256, WPC) void gemm_nt_pipe_kernel(const NtArgs p) {
+// BN: columns of the workgroup tile (128 = four waves, 256 = eight waves: 512 threads, 256 x 256 with BM = 256 - A is then fetched
+// by 4 instead of 8 column blocks and 32 KB are staged per 192 MFMAs where the 256 x 128 tile stages 24 KB per 96)
+template <int BKP, int WPC, int SPLIT = 0, int BM = 128, int BN = 128>
+__global__ __launch_bounds__((BN / 64) * 128, WPC) void gemm_nt_pipe_kernel(const NtArgs p) {
+    constexpr int WN = BN / 64, NTHR = WN * 128;                   // waves along N (two along M), threads
     constexpr bool BF3 = SPLIT != 0;
     constexpr int NPL = SPLIT ? SPLIT : 3;
-    constexpr int PLA = BM * BF3_RS, PLB = 128 * BF3_RS;           // dwords: one term plane of A / of W
+    constexpr int PLA = BM * BF3_RS, PLB = BN * BF3_RS;            // dwords: one term plane of A / of W
     constexpr int OPA = NPL * PLA, OPB = NPL * PLB;                // dwords: one operand buffer
     static_assert(!BF3 || BKP == 16, "the split forms take one 16-deep k block per chunk");
-    static_assert(BF3 || BM == 128, "the fp32 form has the 128-row tile only");
-    constexpr int BN = 128, TM = BM / 64, TN = 2;
+    static_assert(BF3 || (BM == 128 && BN == 128), "the fp32 form has the 128 x 128 tile only");
+    constexpr int TM = BM / 64, TN = 2;
     constexpr int LDP = BKP + 4;                 // LDS row stride (floats): 16 rows x 16 B cover the 64 banks once for 36 and for 20
-    constexpr int TPR = BKP / 4, RPP = 256 / TPR, NL = 128 / RPP, NLA = BM / RPP;      // loader: threads per row, rows per pass, passes (W / A)
+    constexpr int TPR = BKP / 4, RPP = NTHR / TPR, NL = BN / RPP, NLA = BM / RPP;      // loader: threads per row, rows per pass, passes (W / A)
     extern __shared__ float smem[];
     float *sA = smem;                                             // [2][BM][LDP]
     float *sB = smem + (BF3 ? 2 * OPA : 2 * BM * LDP);            // [2][BN][LDP]
     unsigned *uA = reinterpret_cast<unsigned *>(sA), *uB = reinterpret_cast<unsigned *>(sB);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int lr = lane & 31, lh = lane >> 5;
     const int nbn = (p.N + BN - 1) / BN;
     const int64_t total = (int64_t)((p.M + BM - 1) / BM) * nbn, per_xcd = (total + 7) / 8;
@@ -875,6 +878,17 @@ static hipError_t launch_nt_pipe(const NtArgs &a, hipStream_t st, bool fp16x2_ok
         static const int bm = getenv("DAGNET_H2_BM") ? atoi(getenv("DAGNET_H2_BM")) : 256;
         // 256 x 128 tiles (74 KB of LDS, two workgroups per CU) where the k loop is long: 1920 -> 960 298 against 281-291 TFLOP/s at
         // 122 880 rows; the short layers (K = 32, 64) are bound by writing C and lose with the larger tile (126 against 114 us)
+        static const int bn = getenv("DAGNET_H2_BN") ? atoi(getenv("DAGNET_H2_BN")) : 256;
+        if (bm == 256 && bn == 256 && a.M >= 4096 && a.K >= 256 && a.N >= 512) {       // 256 x 256, eight waves, 98 KB of LDS: one workgroup per CU
+            constexpr size_t LDS = split_lds(2, 256, 256);
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_pipe_kernel<16, 1, 2, 256, 256>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+            if (attr != hipSuccess) return attr;
+            const int64_t t = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256);
+            const int64_t blocks = std::min<int64_t>((t + 7) / 8 * 8, 256);
+            hipLaunchKernelGGL((gemm_nt_pipe_kernel<16, 1, 2, 256, 256>), dim3((unsigned)blocks), dim3(512), LDS, st, a);
+            return hipGetLastError();
+        }
         if (bm == 256 && a.M >= 4096 && a.K >= 256) {
             constexpr size_t LDS = split_lds(2, 256);
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_nt_pipe_kernel<16, 2, 2, 256>),

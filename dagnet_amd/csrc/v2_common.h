@@ -437,6 +437,9 @@ __device__ __forceinline__ float attn_weights(T16 &alpha, float s1, const float 
 // Sum over the 8 consecutive lanes of a head (lanes 8p .. 8p+7), the result in all 8: three DPP adds, no LDS round trip
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
+    // no contraction: with it, v = a * b turns the add into v_fmac(dpp(v), a, b) behind a separate v_mov_b32_dpp - three
+    // instructions (v_mul, v_mov_dpp, v_fmac) where v_mul + v_add_f32_dpp do
+#pragma clang fp contract(off)
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 __device__ __forceinline__ float red8(float v) {

@@ -41,6 +41,11 @@ struct WBuf {
         const f32x4 v = dn_buffer_load_f32x4(rs, voff_bytes, soff_floats * 4, 0);
         return make_float4(v.x, v.y, v.z, v.w);
     }
+    // the scalar offset in BYTES, already opaque (wload_half: a compile-time segment offset then costs one s_mov, not s_mov + s_lshl)
+    __device__ __forceinline__ float4 ld4b(int voff_bytes, int soff_bytes) const {
+        const f32x4 v = dn_buffer_load_f32x4(rs, voff_bytes, soff_bytes, 0);
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
     __device__ __forceinline__ float ld1(int voff_bytes, int soff_floats) const {
         return dn_buffer_load_f32(rs, voff_bytes, soff_floats * 4, 0);
     }
@@ -99,9 +104,10 @@ struct WBlk {
 };
 // the two quads of one half block into slot d
 __device__ __forceinline__ void wload_half(WBlk &b, int d, const WBuf &wp, int off, int lane) {
-    asm volatile("" : "+s"(off));     // keep the scalar offset out of loop-invariant hoisting (SGPR spills)
+    int ob = off * 4;
+    asm volatile("" : "+s"(ob));      // keep the scalar offset out of loop-invariant hoisting (SGPR spills)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) b.v[2 * d + j] = wp.ld4(lane * 16 + j * 1024, off);
+    for (int j = 0; j < 2; ++j) b.v[2 * d + j] = wp.ld4b(lane * 16 + j * 1024, ob);
 }
 template <bool BF = false>
 __device__ __forceinline__ WBlk wload(const WBuf &wp, int off, int lane) {

@@ -145,11 +145,11 @@ __device__ __forceinline__ f16x8 as_h8(float4 v) { return __builtin_bit_cast(f16
 struct XSplit {
     float4 t[2];
 };
-__device__ __forceinline__ float split_m1() {
-    float m = -1.0f;
-    asm volatile("" : "+s"(m));
-    return m;
-}
+// -1.0 as a value the compiler cannot fold: a weak constant-memory variable (it may not assume a weak symbol's initialiser),
+// read once per kernel into an SGPR.  (An opaque copy of the literal per call, `asm volatile("" : "+s"(m))`, cost an s_mov and
+// a hazard s_nop behind every inline asm: ~150 of each per wave-step.)
+__attribute__((weak)) __constant__ float v2_minus_one = -1.0f;
+__device__ __forceinline__ float split_m1() { return v2_minus_one; }
 __device__ __forceinline__ void split2(const T16 &x, int p, XSplit &s) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
@@ -169,7 +169,12 @@ __device__ __forceinline__ void split2(const T16 &x, int p, XSplit &s) {
 #ifndef DN_V2_SPLIT_SUB
         h2 lo;
         _Float16 l0 = (_Float16)__builtin_fmaf((float)hi[0], m1, v0);
+#ifndef DN_V2_NO_SLP
+        // (built with the SLP vectoriser: keep it from pairing the two fmas.  The Makefile builds this object without it and
+        // defines DN_V2_NO_SLP - the opaque copy reads a register that v_fma_mixlo_f16 has just written in part, which costs
+        // a wait state each: 300 s_nop per wave-step)
         asm("" : "+v"(l0));
+#endif
         lo[0] = l0;
         lo[1] = (_Float16)__builtin_fmaf((float)hi[1], m1, v1);
 #else
@@ -487,12 +492,20 @@ __device__ __forceinline__ WBlk gat(const T16 (&x)[KT], T16 (&out)[NT], const WB
     constexpr int BS = BF ? V2_BLOCK_SPLIT : V2_BLOCK_F32;
     pre = mm<1, KT, true, BF>(whT, wp, Gw.heads, x, lane, pre, Gw.out);
     ph(10);
+    // stage by stage over all 32 values: a DPP read needs two wait states behind the VALU write of its source, which the next
+    // values' instructions fill (value by value the compiler padded every step of every chain with an s_nop)
     float u1[16], u2[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        u1[r] = red8(whT[0][r] * a_src);
-        u2[r] = red8(whT[0][r] * a_dst);
+        u1[r] = whT[0][r] * a_src;
+        u2[r] = whT[0][r] * a_dst;
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { u1[r] = dpp_add<0xB1>(u1[r]); u2[r] = dpp_add<0xB1>(u2[r]); }      // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { u1[r] = dpp_add<0x4E>(u1[r]); u2[r] = dpp_add<0x4E>(u2[r]); }      // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { u1[r] = dpp_add<0x141>(u1[r]); u2[r] = dpp_add<0x141>(u2[r]); }    // row_half_mirror
     // register r = 4a + i of half lh is tile row i + 8a + 4 lh: the first lane of every head writes its 16 rows of s1, every
     // lane picks up its own row's four values, then the same 128 floats carry s2 (read by everybody in the head loop)
     __syncthreads();

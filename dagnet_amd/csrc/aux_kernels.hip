@@ -204,9 +204,35 @@ __global__ void dn_categorical_kernel(int N, int G, const float *__restrict__ w,
     if (row >= N) return;
     float best = -1.f;
     int bi = 0x7fffffff;
+    if (!q) {
+        // in-kernel stream: one uniform per row, inverse of the cumulative weights (rng.h rng_draw_u); lane l sums the chunk
+        // [l len, (l + 1) len) of the columns, the last lane whose chunk starts at or below u * total resolves the column
+        const int len = (G + 63) / 64, g0 = min(lane * len, G), g1 = min(g0 + len, G);
+        const float *wr = w + (int64_t)row * G;
+        float mine = 0.f;
+        for (int g = g0; g < g1; ++g) mine += fmaxf(wr[g], 0.f);
+        float inc = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const float up = __shfl_up(inc, o);
+            inc += lane >= o ? up : 0.f;
+        }
+        const float before = inc - mine, target = rng_draw_u(seed, (uint32_t)row, 0u) * __shfl(inc, 63);
+        int cand = -1;
+        if (g0 < g1 && before <= target) {
+            float c = before;
+            for (int g = g0; g < g1; ++g) {         // the column where the sum passes the target, else the chunk's last positive one
+                const float wv = fmaxf(wr[g], 0.f);
+                c += wv;
+                if (wv > 0.f) cand = g;
+                if (c > target) break;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) cand = max(cand, __shfl_xor(cand, o));
+        if (lane == 0) out[row] = max(cand, 0);
+        return;
+    }
     for (int g = lane; g < G; g += 64) {
-        const float qq = q ? q[(int64_t)row * G + g] : rng_exp1(seed, (uint32_t)row, 0u, (uint32_t)g);
-        const float v = w[(int64_t)row * G + g] / qq;
+        const float v = w[(int64_t)row * G + g] / q[(int64_t)row * G + g];
         if (v > best) { best = v; bi = g; }
     }
     for (int o = 32; o > 0; o >>= 1) {

@@ -33,6 +33,17 @@ __device__ __forceinline__ uint32_t rng_bits(uint64_t seed, uint32_t stream, uin
 __device__ __forceinline__ float rng_uniform(uint64_t seed, uint32_t row, uint32_t t, uint32_t j) {
     return (float)(rng_bits(seed, 0, row, t, j) >> 8) * (1.0f / 16777216.0f);
 }
+// The goal draw of the in-kernel stream (round 3): ONE uniform per (row, t) - word 0 of block (row, t, 0, stream 1) - and the
+// inverse of the cumulative weights: goal = min { j : w_0 + .. + w_j > u * (w_0 + .. + w_{G-1}) }.  An exact categorical sample
+// like the exponential race argmax_j w_j / q_j that torch.multinomial runs (and that the kernels keep for INJECTED q, which is
+// what parity with the reference is defined on), for 1 Philox block and G additions instead of G / 4 blocks and 2 G logarithms.
+// Every kernel adds the weights in the order its layout gives; two kernels then differ only where u * total falls within
+// rounding of a boundary (~1e-5 of the draws; the kernels' softmax values differ at that level anyway).
+// 23 random bits + 1/2: exact in fp32 and strictly inside (0, 1).
+__device__ __forceinline__ float rng_draw_u(uint64_t seed, uint32_t row, uint32_t t) {
+    const uint4 r = philox4x32(make_uint4(row, t, 0u, 1u), make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    return ((float)(r.x >> 9) + 0.5f) * (1.0f / 8388608.0f);
+}
 __device__ __forceinline__ float rng_exp1(uint64_t seed, uint32_t row, uint32_t t, uint32_t j) {
     const float u = ((float)(rng_bits(seed, 1, row, t, j) >> 8) + 1.0f) * (1.0f / 16777216.0f);   // (0,1]
     return -logf(u) + 1e-30f;

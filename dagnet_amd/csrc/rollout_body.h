@@ -687,20 +687,55 @@ __device__ __forceinline__ void run_tile(const DnCtx &P, const int tile) {
             if (MODE == MODE_FORWARD) {
                 if (sl == 0 && live) ce_acc -= (double)MEM(L.gcomb + ri_gidx[m] * M + m);
             } else {
-                // categorical draw: argmax_g exp(p_g) / q_g   (first maximum wins)
+                // categorical draw.  Injected q: argmax_g exp(p_g) / q_g (first maximum wins) - torch.multinomial's exponential race.
+                // In-kernel stream: one uniform per row and step, inverse of the cumulative weights (rng.h rng_draw_u): slice sl
+                // sums the chunk [sl len, (sl + 1) len) of the features; the chunk whose cumulative range holds u * total
+                // resolves the feature (the LAST slice whose range starts at or below the target wins).
                 float best = -1.f;
                 int bi = 0;
-                if (live) {
-                    const int64_t qb = (((int64_t)krow * R.T + t) * NK + grow) * D.G;
-                    for (int g = sl; g < D.G; g += nsl) {
-                        const float qq = R.q ? R.q[qb + g] : rng_exp1(R.seed, (uint32_t)(krow * R.N + grow), t, g);
-                        const float v = expf(MEM(L.gcomb + g * M + m)) / qq;
-                        if (v > best) { best = v; bi = g; }
+                if (R.q) {
+                    if (live) {
+                        const int64_t qb = (((int64_t)krow * R.T + t) * NK + grow) * D.G;
+                        for (int g = sl; g < D.G; g += nsl) {
+                            const float v = expf(MEM(L.gcomb + g * M + m)) / R.q[qb + g];
+                            if (v > best) { best = v; bi = g; }
+                        }
                     }
+                    MEM(L.red + sl * M + m) = best;
+                    reinterpret_cast<int *>(smem + L.red)[(nsl + sl) * M + m] = bi;
+                    __syncthreads();
+                } else {
+                    const int len = (D.G + nsl - 1) / nsl, g0 = min(sl * len, D.G), g1 = min(g0 + len, D.G);
+                    float mysum = 0.f;
+                    if (live)
+                        for (int g = g0; g < g1; ++g) mysum += expf(MEM(L.gcomb + g * M + m));
+                    MEM(L.red + sl * M + m) = mysum;
+                    __syncthreads();
+                    float before = 0.f, total = 0.f;
+                    for (int i = 0; i < nsl; ++i) {
+                        const float v = MEM(L.red + i * M + m);
+                        before += i < sl ? v : 0.f;
+                        total += v;
+                    }
+                    __syncthreads();                 // L.red is rewritten below
+                    int cand = -1;                   // this slice's answer if the target lies at or beyond its range's start
+                    if (live && g0 < g1) {
+                        const float target = rng_draw_u(R.seed, (uint32_t)(krow * R.N + grow), (uint32_t)t) * total;
+                        if (before <= target) {
+                            float c = before;
+                            cand = g1 - 1;
+                            for (int g = g0; g < g1; ++g) {
+                                c += expf(MEM(L.gcomb + g * M + m));
+                                if (c > target) { cand = g; break; }
+                            }
+                        }
+                    }
+                    MEM(L.red + sl * M + m) = (float)cand;                       // the slices' ranges increase with sl: the largest candidate is the draw
+                    reinterpret_cast<int *>(smem + L.red)[(nsl + sl) * M + m] = cand;
+                    best = (float)cand;
+                    bi = max(cand, 0);
+                    __syncthreads();
                 }
-                MEM(L.red + sl * M + m) = best;
-                reinterpret_cast<int *>(smem + L.red)[(nsl + sl) * M + m] = bi;
-                __syncthreads();
                 if (sl == 0 && live) {
                     for (int i = 1; i < nsl; ++i) {
                         const float v = MEM(L.red + i * M + m);

@@ -323,36 +323,83 @@ __global__ __launch_bounds__(64, DN_V2_OCC) void rollout_v2_kernel(const V2Weigh
             int bi = 0x7fffffff;
             const int Gm1 = R.G - 1;
             const int64_t qrow = row_t * R.G;
+            if (R.q) {          // injected q (parity with the reference's torch.multinomial): the exponential race
 #pragma unroll
-            for (int nt = 0; nt < GT; ++nt)
+                for (int nt = 0; nt < GT; ++nt)
 #pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const int f0 = nt * 32 + 8 * a + 4 * lh;
-                    float lq[4];          // log2(q) up to a constant
-                    if (R.q) {      // uniform branch; loads are clamped into the row instead of predicated
+                    for (int a = 0; a < 4; ++a) {
+                        const int f0 = nt * 32 + 8 * a + 4 * lh;
+                        float lq[4];          // log2(q) up to a constant; loads are clamped into the row instead of predicated
 #pragma unroll
                         for (int i = 0; i < 4; ++i) lq[i] = __builtin_amdgcn_logf(R.q[qrow + min(f0 + i, Gm1)]);
-                    } else {
-                        const uint4 u = philox4x32(make_uint4(rrow, (uint32_t)tq, (uint32_t)(f0 >> 2), 1u),
-                                                      make_uint2((uint32_t)R.seed, (uint32_t)(R.seed >> 32)));
-                        const uint32_t u4[4] = {u.x, u.y, u.z, u.w};
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) lq[i] = __builtin_amdgcn_logf(24.0f - __builtin_amdgcn_logf((float)(u4[i] >> 8) + 1.0f));
+                        for (int i = 0; i < 4; ++i) {
+                            const int f = f0 + i;
+                            float v = gc[nt][4 * a + i] * pscale - lq[i];
+                            v = f <= Gm1 ? v : -INFINITY;
+                            const bool take = v > best;
+                            best = take ? v : best;
+                            bi = take ? f : bi;
+                        }
                     }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int f = f0 + i;
-                        float v = gc[nt][4 * a + i] * pscale - lq[i];
-                        v = f <= Gm1 ? v : -INFINITY;
-                        const bool take = v > best;
-                        best = take ? v : best;
-                        bi = take ? f : bi;
-                    }
-                }
-            {
                 const float ov = xhalf(best);
                 const int oi = xhalf(bi);
                 if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+            } else {
+                // in-kernel stream: one uniform per row and step, inverse of the cumulative weights (rng.h rng_draw_u): one Philox
+                // block, G exp2 and ~3 G additions / selects where the race took G / 4 blocks and 2 G logarithms - the draw
+                // was 1 500 of the step's 8 700 VALU instructions.  Order of the sum: the groups of four consecutive features
+                // a lane half holds, ((w0 + w1) + w2) + w3, then the 8 GT groups in feature order (both halves add the same
+                // numbers in the same order, so they agree on the group; the half that holds it resolves the feature).
+                constexpr int NG = 4 * GT;          // groups per half
+                float gs[NG];
+#pragma unroll
+                for (int nt = 0; nt < GT; ++nt)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const int f0 = nt * 32 + 8 * a + 4 * lh;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float w = __builtin_amdgcn_exp2f(gc[nt][4 * a + i] * pscale);      // exp(p), p the softmax probability
+                            gc[nt][4 * a + i] = f0 + i <= Gm1 ? w : 0.f;
+                        }
+                        gs[nt * 4 + a] = ((gc[nt][4 * a] + gc[nt][4 * a + 1]) + gc[nt][4 * a + 2]) + gc[nt][4 * a + 3];
+                    }
+                float pre[2 * NG];                  // inclusive prefix over the groups in feature order: k = 2 (4 nt + a) + half
+                float run = 0.f;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const float og = xhalf(gs[g]);
+                    run += lh ? og : gs[g];
+                    pre[2 * g] = run;
+                    run += lh ? gs[g] : og;
+                    pre[2 * g + 1] = run;
+                }
+                const float target = rng_draw_u(R.seed, rrow, (uint32_t)tq) * run;
+                int ks = 0;                         // groups that end at or below the target: the draw lies in group ks
+                float base = 0.f;
+#pragma unroll
+                for (int k = 0; k < 2 * NG - 1; ++k) {
+                    const bool below = pre[k] <= target;
+                    ks += below ? 1 : 0;
+                    base = below ? pre[k] : base;
+                }
+                const int mine = ks >> 1;           // the group's index in its half
+                float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < GT; ++nt)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const bool hit = mine == nt * 4 + a;
+                        w0 = hit ? gc[nt][4 * a] : w0;
+                        w1 = hit ? gc[nt][4 * a + 1] : w1;
+                        w2 = hit ? gc[nt][4 * a + 2] : w2;
+                    }
+                const float c0 = base + w0, c1 = c0 + w1, c2 = c1 + w2;
+                const int in = (c0 <= target ? 1 : 0) + (c1 <= target ? 1 : 0) + (c2 <= target ? 1 : 0);
+                const int f = (mine >> 2) * 32 + (mine & 3) * 8 + (ks & 1) * 4 + in;
+                const int of = xhalf(f);
+                bi = (ks & 1) == lh ? f : of;
             }
             if (R.force_goals && live) bi = min(max(R.force_goals[row_t], 0), R.G - 1);
             gi = min(bi, R.G - 1);

@@ -269,21 +269,41 @@ __global__ void draw_kernel(int N, int K, int T, int t, int G, const float *__re
         }
         s = wave_sum(s);
         const float pscale = LOG2E / s;
-        const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+        // in-kernel stream: one uniform per row and step, inverse of the cumulative weights w_c = exp(p_c) (rng.h rng_draw_u) in
+        // column order - piece i of lane l holds columns 4 (64 i + l) .. + 3, so the order is piece-major, lanes within a piece
+        float ps[4], excl[4], tot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool on = lane + 64 * i < (G >> 2);
+            x[i].x = on ? __builtin_amdgcn_exp2f(x[i].x * pscale) : 0.f;
+            x[i].y = on ? __builtin_amdgcn_exp2f(x[i].y * pscale) : 0.f;
+            x[i].z = on ? __builtin_amdgcn_exp2f(x[i].z * pscale) : 0.f;
+            x[i].w = on ? __builtin_amdgcn_exp2f(x[i].w * pscale) : 0.f;
+            ps[i] = ((x[i].x + x[i].y) + x[i].z) + x[i].w;
+            float inc = ps[i];                          // inclusive scan over the lanes
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const float up = __shfl_up(inc, o);
+                inc += lane >= o ? up : 0.f;
+            }
+            excl[i] = tot + (inc - ps[i]);
+            tot += __shfl(inc, 63);
+        }
+        const float target = rng_draw_u(seed, (uint32_t)r, (uint32_t)t) * tot;
+        // every piece that starts at or below the target proposes the column where its own cumulative sum passes it (its last
+        // column if it never does); starts increase with the column, so the largest proposal is the draw
+        bi = -1;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c4 = lane + 64 * i;
-            if (c4 >= (G >> 2)) break;
-            const uint4 rb = philox4x32(make_uint4((uint32_t)r, (uint32_t)t, (uint32_t)c4, 1u), key);
-            const float xs[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
-            const uint32_t bs[4] = {rb.x, rb.y, rb.z, rb.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float n = (float)(bs[e] >> 8) + 1.0f;                     // q = -ln(n / 2^24)
-                const float v = xs[e] * pscale - __builtin_amdgcn_logf(24.0f - __builtin_amdgcn_logf(n));
-                if (v > best) { best = v; bi = 4 * c4 + e; }                    // columns increase: the first maximum wins
+            if (c4 < (G >> 2) && excl[i] <= target) {
+                const float c0 = excl[i] + x[i].x, c1 = c0 + x[i].y, c2 = c1 + x[i].z;
+                bi = max(bi, 4 * c4 + (c0 <= target ? 1 : 0) + (c1 <= target ? 1 : 0) + (c2 <= target ? 1 : 0));
             }
         }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) bi = max(bi, __shfl_xor(bi, o));
+        best = INFINITY;            // the reduction below keeps this lane's bi (all lanes hold the same)
     } else {
         float mx = -INFINITY;
         for (int c = lane; c < G; c += 64) mx = fmaxf(mx, p[c]);

@@ -242,6 +242,43 @@ def test_utils_match_oracle():
     assert abs(evaluate_helper(errs, sse).item() - want.item()) < 1e-5
 
 
+def test_seeded_goal_draws_follow_the_weights():
+    """The in-kernel stream draws a goal from ONE uniform per row by inverting the cumulative weights (csrc/rng.h rng_draw_u) - an
+    exact categorical sample like torch.multinomial's exponential race.  (a) The stand-alone draw: frequencies over 400 000 rows
+    against the weights, zero-weight columns never drawn, every column index reachable, ragged widths.  (b) The rollout kernels'
+    draw of exp(softmax probabilities): goal frequencies of the register-resident and of the generic kernel over the same seeds
+    agree with each other within sampling noise."""
+    from dagnet_amd import utils
+    for G in (7, 90, 961):
+        g = torch.Generator().manual_seed(G)
+        w1 = torch.rand(G, generator=g) ** 3
+        w1[G // 2] = 0.0
+        w1[-1] = 0.0
+        N = 400_000
+        oh = utils.sample_multinomial(w1.expand(N, G).contiguous().to(DEV), seed=17 + G)
+        cnt = oh.sum(0).double().cpu()
+        assert cnt.sum().item() == N and cnt[G // 2].item() == 0 and cnt[-1].item() == 0
+        pr = (w1 / w1.sum()).double()
+        z = (cnt - N * pr) / (N * pr * (1 - pr)).clamp_min(1e-12).sqrt()
+        big = N * pr >= 50                  # the normal approximation needs an expected count; rarer columns: only "not too often"
+        assert float(z[big].abs().max()) < 5.5, float(z[big].abs().max())
+        assert bool((cnt[~big] <= 50 + 6 * 50 ** 0.5).all())
+        again = utils.sample_multinomial(w1.expand(N, G).contiguous().to(DEV), seed=17 + G)
+        assert torch.equal(oh, again)
+    a, m, _ = _model("dagnet", n_layers=2)
+    sizes = [10] * 300
+    batch = [t.to(DEV) for t in syn.make_batch(sizes, 10, 12, 3)]
+    h = (syn.uniform_noise(3, "h0", (a.n_layers, 3000, 64)) - 0.5).to(DEV)
+    _, g_v2 = _sample_k("dagnet", m, 4, 12, h, batch, seed=5, return_goals=True)
+    with generic_kernel():
+        _, g_gen = _sample_k("dagnet", m, 4, 12, h, batch, seed=5, return_goals=True)
+    assert (g_v2 == g_gen).float().mean().item() > 0.999
+    f1 = torch.bincount(g_v2.flatten().long(), minlength=a.g_dim).double()
+    assert int((f1 > 0).sum()) > a.g_dim // 2, "the draws cover only a few goals"
+    # the weights exp(p), p in [0, 1], are within a factor e of each other: no goal may dominate
+    assert float(f1.max() / f1.sum()) < 5.0 / a.g_dim
+
+
 def test_evaluate_end_to_end():
     """evaluate() over a 2-batch loader = forward + K rollouts + min-over-K metrics, per the reference's formulae."""
     from dagnet_amd.evaluate import evaluate, rollout_best_of_k

@@ -645,17 +645,28 @@ def main():
             "forward_obs_ms": fwd_ms, "steps_requested": steps_requested, "warmup_requested": warmup_requested,
             "ade": float(tot[0] / (tot[2] * T)), "fde": float(tot[1] / tot[2]),
         }
-        if split and split[0] == "fp16x2" and wl["kind"] == "dagnet" and "register-resident" in info["sample_kernel"] and (wl["agents"] or 0) == 10:
-            # what bounds the split kernel: the SIMD's vector issue port.  Static instruction counts of one wave-step of
-            # rollout_v2_kernel<2,2,32,1,true> (tools/isa_mix.py; SQ_INSTS_MFMA of profiles/r03_pmc.json agrees with the MFMA count)
-            # priced with the issue costs of MI355X_MICROARCH.md, against the measured clocks per wave-step and SIMD at the clock
-            # the chip holds under this kernel (profiles/r03_clock_under_load_fp16x2.txt)
-            ghz = 1.99
-            need = 8774 * 4 + 1004 * 8 + 942 * 8 + 531 * 4
-            have = kernel_ms * 1e-3 * ghz * 1e9 * 1024 / (info["n_tiles"] * T)
-            line["roofline"]["vector_issue"] = {"clocks_needed_per_wave_step": need, "clocks_measured_per_wave_step_and_simd": have,
-                                                "frac": need / have, "mfma_pipe_clocks_per_wave_step": 942 * 32, "clock_ghz": ghz,
-                                                "note": "8774 VALU x 4 + 1004 transcendental x 8 + 942 MFMA x 8 + 531 s_nop x 4 issue clocks"}
+        if split and split[0] == "fp16x2" and opt.workload == "dagnet_bsk_4096x20":
+            # what bounds the split kernel: the SIMD's vector issue port, not the matrix pipe.  From the committed counter
+            # passes of this workload (profiles/*_pmc.json: instructions and cycles of the full-size launches) priced with the issue
+            # costs of MI355X_MICROARCH.md: 4 clocks per VALU instruction, 8 per transcendental and per MFMA; cycles, not time -
+            # the clock under this kernel varies between boxes (1.88 - 1.99 GHz, profiles/r03_clock_under_load_fp16x2.txt)
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), reverse=True):
+                try:
+                    ks = json.load(open(path))[opt.workload]["kernels"]
+                    c = next(v for k_, v in ks.items() if "rollout_v2_kernel<2, 2, 32, 1, true>" in k_)
+                    ws = float(info["n_tiles"] * T)
+                    mfma, vec = c["SQ_INSTS_MFMA"] / ws, (c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]) / ws
+                    trans = 908.0            # v_exp / v_rcp / v_log of one wave-step (tools/isa_mix.py on the seed-mode path)
+                    need = (vec - trans) * 4 + trans * 8 + mfma * 8
+                    have = c["GRBM_GUI_ACTIVE"] / 8 * 1024 / ws
+                    line["roofline"]["vector_issue"] = {
+                        "vector_instructions_per_wave_step": vec, "mfma_per_wave_step": mfma, "issue_clocks_needed": need,
+                        "clocks_measured_per_wave_step_and_simd": have, "frac": need / have, "mfma_pipe_frac": mfma * 32 / have,
+                        "source": os.path.basename(path)}
+                    break
+                except (OSError, ValueError, KeyError, StopIteration):
+                    continue
         if split_bf16 and n_chunks == 1 and not opt.no_reference_loop:
             # the same launch with the products on fp32 MFMAs (untimed leg, 2 launches): the fp32-matrix roofline of round 2
             _ops.set_fused(_ops.set_fused(-1) & ~8)

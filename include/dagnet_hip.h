@@ -98,7 +98,9 @@ int dagnet_plan_kernel(const dagnet_plan *p);
  *   d_x0      [N,2]     last observed absolute position        (A-VRNN, DAG-Net; else NULL)
  *   d_g0      int32[N]  last observed goal index               (DAG-Net; else NULL)
  *   d_eps     [K,T,N,Z] injected U[0,1) noise, or NULL -> Philox stream from `seed`
- *   d_q       [K,T,N,G] injected Exp(1) variates for the goal draw (DAG-Net), or NULL
+ *   d_q       [K,T,N,G] injected Exp(1) variates for the goal draw (DAG-Net): goal = argmax_g w_g / q_g, torch.multinomial's
+ *                       exponential race; or NULL -> one uniform per (sample, step, row) from the Philox stream of `seed` and
+ *                       the inverse of the cumulative weights (the same categorical distribution, csrc/rng.h rng_draw_u)
  *   d_force_goals int32[K,T,N] or NULL: overrides the categorical draw (tests)
  *   d_out     [K,T,N,2] predicted displacements (the reference's `samples`)
  *   d_out_goals int32[K,T,N] or NULL: sampled goal index per step (DAG-Net)
@@ -179,8 +181,9 @@ int dagnet_displacement_errors(int32_t T, int32_t N, const float *d_pred, const 
                                float *d_ade, float *d_fde, void *stream);
 
 /* Replaces: sample_multinomial's torch.multinomial(probs, 1) (models/utils/utils.py:200-207):
- * d_out[n] = argmax_g d_weights[n,g] / q[n,g] with q ~ Exp(1) taken from d_q [N,G] or, when
- * d_q is NULL, from the Philox stream of `seed`. */
+ * d_out[n] = argmax_g d_weights[n,g] / q[n,g] with q ~ Exp(1) taken from d_q [N,G]; when d_q is NULL, one uniform u per row from
+ * the Philox stream of `seed` and d_out[n] = min { g : w_0 + .. + w_g > u (w_0 + .. + w_{G-1}) } (negative weights count as 0;
+ * a column of weight 0 is never drawn) - the same distribution. */
 int dagnet_categorical(int32_t N, int32_t G, const float *d_weights, const float *d_q, uint64_t seed,
                        int32_t *d_out, void *stream);
 

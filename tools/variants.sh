@@ -10,7 +10,7 @@ OTHERS=$(ls $LIB/obj/*.o | grep -v rollout_v2_bf3.o)
 mkdir -p $LIB/var
 while [ $# -ge 2 ]; do
   TAG=$1; FLAGS=$2; shift 2
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-pass-failed -fno-honor-nans -DDN_V2_BF=1 -DDN_V2_ONLY $FLAGS -c -o $LIB/var/$TAG.o rollout_v2.hip &&
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-pass-failed -fno-honor-nans -DDN_V2_BF=1 -DDN_V2_ONLY -fno-slp-vectorize -DDN_V2_NO_SLP $FLAGS -c -o $LIB/var/$TAG.o rollout_v2.hip &&
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $LIB/libdagnet_hip_$TAG.so $OTHERS $LIB/var/$TAG.o && echo built $TAG ) &
 done
 wait

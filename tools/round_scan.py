@@ -15,7 +15,7 @@ wl = bench.WORKLOADS["dagnet_bsk_4096x20"]
 dev = torch.device("cuda", 0)
 a, model = bench.build(wl, dev)
 K = 20
-for S, T in ((1536, 40), (3072, 40), (4096, 40), (4608, 40), (3072, 20), (3072, 80), (153, 40), (307, 40)):
+for S, T in ((1536, 40), (3072, 40), (4096, 40), (4608, 40), (3072, 20), (3072, 80), (153, 40), (307, 40), (307, 400), (153, 400), (614, 400)):
     obs, gt, obs_rel, gt_rel, og, gg, sse = [t.to(dev) for t in syn.make_batch([10] * S, 10, T, 5)]
     h = torch.rand(a.n_layers, S * 10, a.rnn_dim, device=dev) - 0.5
     g0 = og[-1].to(torch.int32)

@@ -16,16 +16,29 @@ _ADJ = {0: 0, 1: 1, 2: 2}
 _GRAPH = {None: 0, "gat": _capi.GRAPH_GAT, "gcn": _capi.GRAPH_GCN}
 
 
+_sse_cache: dict = {}
+_goal_cache: dict = {}
+
+
 def scene_ptr_from_sse(seq_start_end, n_rows: Optional[int] = None) -> np.ndarray:
     """The reference's seq_start_end [[start,end],...] -> CSR pointer int32[S+1].
 
     Scenes must tile the rows contiguously (they do for every loader of the reference:
     models/dagnet/data/loader_bsk.py:12-35, loader_sdd.py:16-42)."""
     if isinstance(seq_start_end, torch.Tensor):
-        if seq_start_end.is_cuda and torch.cuda.is_current_stream_capturing():
-            raise ValueError("under hipGraph capture pass seq_start_end as a host tensor or list "
-                             "(a device tensor would need a blocking copy, which a capturing stream refuses)")
-        sse = seq_start_end.detach().cpu().numpy()
+        if seq_start_end.is_cuda:
+            # a device tensor costs a blocking copy per call, which would also serialise the launches of a loop of sample()
+            # calls (_capi._overlap_stream): the last one is remembered by storage and version counter
+            key = (seq_start_end.data_ptr(), seq_start_end._version, tuple(seq_start_end.shape), n_rows)
+            if _sse_cache.get("key") == key:
+                return _sse_cache["ptr"]
+            if torch.cuda.is_current_stream_capturing():
+                raise ValueError("under hipGraph capture pass seq_start_end as a host tensor or list "
+                                 "(a device tensor would need a blocking copy, which a capturing stream refuses)")
+            ptr = scene_ptr_from_sse(seq_start_end.detach().cpu().numpy(), n_rows)
+            _sse_cache.update(key=key, ptr=ptr, ref=seq_start_end)      # the reference keeps the address from being reused
+            return ptr
+        sse = seq_start_end.detach().numpy()
     else:
         sse = np.asarray(seq_start_end)
     sse = sse.reshape(-1, 2).astype(np.int64)
@@ -118,8 +131,19 @@ class HipBacked:
 
 def as_goal_index(g: torch.Tensor, g_dim: int) -> torch.Tensor:
     """one-hot [.., G] float (the reference's goals_ohe) or integer indices [..] -> int32 indices."""
-    if g.dtype in (torch.int32, torch.int64, torch.int16, torch.uint8):
-        return g.to(torch.int32)
-    if g.shape[-1] != g_dim:
-        raise ValueError(f"goal tensor must be one-hot with last dim {g_dim}, got {tuple(g.shape)}")
-    return g.argmax(-1).to(torch.int32)
+    if g.dtype == torch.int32:
+        return g
+    # the conversion makes a new tensor; a loop that passes the same one-hot tensor again gets the same index tensor back, so that
+    # consecutive sample() calls are seen to start from the same inputs (_capi._overlap_stream)
+    key = (g.data_ptr(), g._version, tuple(g.shape), g.dtype, g_dim)
+    if _goal_cache.get("key") == key:
+        return _goal_cache["idx"]
+    if g.dtype in (torch.int64, torch.int16, torch.uint8):
+        idx = g.to(torch.int32)
+    else:
+        if g.shape[-1] != g_dim:
+            raise ValueError(f"goal tensor must be one-hot with last dim {g_dim}, got {tuple(g.shape)}")
+        idx = g.argmax(-1).to(torch.int32)
+    if g.is_cuda and g.dim() <= 2 and not torch.cuda.is_current_stream_capturing():     # g_start of sample(), not forward()'s [T,N,G]
+        _goal_cache.update(key=key, idx=idx, ref=g)
+    return idx

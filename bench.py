@@ -579,7 +579,7 @@ def main():
 
     # Launches that do not fill the chip several times over (avrnn_bsk_512x20: 3 414 tiles) would be diverted to side streams and
     # overlap with the NEXT step's launch (_capi._overlap_stream): fine for throughput, but the events below would no longer
-    # bracket one launch.  The timed region keeps every launch on this stream; the overlapped rate is reported beside it.
+    # bracket one launch.  The timed region keeps every launch on this stream.
     os.environ["DAGNET_NO_OVERLAP"] = "1"
     for i in range(opt.warmup):
         step(i, False)
@@ -594,16 +594,6 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     del os.environ["DAGNET_NO_OVERLAP"]
-    overlapped_ms = None
-    if n_chunks == 1 and opt.steps:
-        step(0, False)
-        torch.cuda.synchronize()
-        if model.hip_model(dev).__dict__.get("_ovl"):          # this workload's launches are small enough to be diverted
-            t1 = time.perf_counter()
-            for i in range(opt.steps):
-                step(i, False)
-            torch.cuda.synchronize()
-            overlapped_ms = (time.perf_counter() - t1) * 1e3 / opt.steps
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -697,8 +687,6 @@ def main():
             line["roofline"]["fp32_mfma"] = {"ms_per_step": f32_ms, "achieved": launch_flop / (f32_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MATRIX_TFLOPS,
                                              "unit": "TFLOP/s", "frac": launch_flop / (f32_ms * 1e-3) / 1e12 / PEAK_FP32_MATRIX_TFLOPS,
                                              "note": "the same step with DAGNET_NO_BF16X3 semantics (whole step incl. metrics, wall clock)"}
-        if overlapped_ms is not None:
-            line["overlapped_steps_ms_per_step"] = overlapped_ms     # consecutive steps on two side streams (untimed leg)
         if n_chunks == 1 and not opt.no_reference_loop:
             # the reference's evaluation loop AS WRITTEN (models/dagnet/evaluate_bsk.py:113-114): K separate sample() calls
             # (untimed leg; one call first: the K = 1 plan is built once per batch layout).  The calls overlap on the device through

@@ -85,37 +85,9 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
     float *bimg = wimg + NT * KG * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lr = lane & 31, lh = lane >> 5;
-    // ---- weight image (once per workgroup)
-    if (!p.transb && !(p.ldw & 3) && !(reinterpret_cast<uintptr_t>(p.W) & 15)) {
-        // W[n][k .. k+3] is one aligned float4: a quad of the image per load
-        for (int e = tid; e < NT * KG * 64; e += 256) {
-            const int l = e & 63, g = (e >> 6) % KG, nt = (e >> 6) / KG;
-            const int n = nt * 32 + (l & 31), k = g * 8 + 4 * (l >> 5);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.N && k < p.K) {
-                v = *reinterpret_cast<const f32x4 *>(p.W + (int64_t)n * p.ldw + k);      // k + 3 < ldw (ldw is a multiple of 4)
-#pragma unroll
-                for (int i = 1; i < 4; ++i)
-                    if (k + i >= p.K) v[i] = 0.f;
-            }
-            *reinterpret_cast<f32x4 *>(wimg + e * 4) = v;
-        }
-    } else {
-        for (int e = tid; e < NT * KG * 256; e += 256) {
-            const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) % KG, nt = (e >> 8) / KG;
-            const int n = nt * 32 + (l & 31), k = g * 8 + 4 * (l >> 5) + i;
-            float v = 0.f;
-            if (n < p.N && k < p.K) v = p.transb ? p.W[(int64_t)k * p.ldw + n] : p.W[(int64_t)n * p.ldw + k];
-            wimg[e] = v;
-        }
-    }
-    if (tid < NT * 32) bimg[tid] = (p.bias && tid < p.N) ? p.bias[tid] : 0.f;
-    __syncthreads();
-
     const int n_tiles = (p.M + 31) >> 5;
     const int stride = (int)gridDim.x * 4;
     int tile = (int)blockIdx.x * 4 + wave;
-    if (tile >= n_tiles) return;
 
     const i32x4 ra = make_rsrc(p.A, (int64_t)p.M * p.lda * 4), rc = make_rsrc(p.C, (int64_t)p.M * p.ldc * 4);
     const i32x4 rg = make_rsrc(p.gather, 0x7fffffffLL);
@@ -163,7 +135,60 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) dst[g][i] = (8 * g + i < kq) ? dst[g][i] : 0.f;
     };
+    // ---- weight image (once per workgroup): quad e = (nt, g, lane l) holds W[n = 32 nt + (l & 31)][k = 8 g + 4 (l >> 5) + 0..3];
+    // a thread's quads advance by four k-groups per iteration (no division by KG in the loop).  Order of the requests: the
+    // image's quads (L2 hits), then the first tile's rows (HBM), then the image is written to LDS - loads return in order, so
+    // the image is complete while the rows are still on their way, and the rows' latency overlaps the LDS writes and the barrier
+    // instead of starting behind them (a tile past the end reads zeros through the range check).
+    constexpr int QI = (NT * KG * 64 + 255) / 256;
+    f32x4 wv[QI];
+    {
+        const bool quads = !p.transb && !(p.ldw & 3) && !(reinterpret_cast<uintptr_t>(p.W) & 15);
+        int g = wave, nt = 0;
+        while (g >= KG) { g -= KG; ++nt; }
+        auto image = [&](auto load) {
+#pragma unroll
+            for (int q = 0; q < QI; ++q) {
+                const int n = nt * 32 + lr, k = g * 8 + 4 * lh;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (nt < NT && n < p.N && k < p.K) {
+                    v = load(n, k);
+#pragma unroll
+                    for (int i = 1; i < 4; ++i)
+                        if (k + i >= p.K) v[i] = 0.f;
+                }
+                wv[q] = v;
+                g += 4;
+                while (g >= KG) { g -= KG; ++nt; }
+            }
+        };
+        if (quads) {
+            image([&](int n, int k) { return *reinterpret_cast<const f32x4 *>(p.W + (int64_t)n * p.ldw + k); });      // k + 3 < ldw
+        } else if (p.transb) {
+            image([&](int n, int k) {                                   // lanes = consecutive n: coalesced rows of W [K, N]
+                const float *w = p.W + (int64_t)k * p.ldw + n;
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = k + i < p.K ? w[(int64_t)i * p.ldw] : 0.f;
+                return v;
+            });
+        } else {
+            image([&](int n, int k) {
+                const float *w = p.W + (int64_t)n * p.ldw + k;
+                f32x4 v;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = k + i < p.K ? w[i] : 0.f;
+                return v;
+            });
+        }
+    }
     load_rows(cur, tile);
+#pragma unroll
+    for (int q = 0; q < QI; ++q)
+        if (tid + 256 * q < NT * KG * 64) *reinterpret_cast<f32x4 *>(wimg + (tid + 256 * q) * 4) = wv[q];
+    if (tid < NT * 32) bimg[tid] = (p.bias && tid < p.N) ? p.bias[tid] : 0.f;
+    __syncthreads();
+    if (tile >= n_tiles) return;
     while (true) {
         const int ntile = tile + stride;
         const bool more = ntile < n_tiles;
@@ -200,6 +225,9 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
                 for (int r = 0; r < 16; ++r)
                     gpre[nt][r] = sk_load1(rg, gvoff + min(nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, p.N - 1) * gsn4, 0, 0);
         }
+        // one output tile after the other: the stores of tile nt leave while the MFMAs of tile nt + 1 run (with all tiles' MFMAs
+        // first, every wave of the chip computed and then stored at the same time, and neither phase hid the other)
+#ifdef DN_SK_GOUTER
 #pragma unroll
         for (int g = 0; g < KG; ++g)
 #pragma unroll
@@ -209,12 +237,24 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], cur[g][1], acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], cur[g][2], acc[nt], 0, 0, 0);
                 acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], cur[g][3], acc[nt], 0, 0, 0);
-                if (((nt + g * NT) & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // at most two weight quads in flight
+                if (((nt + g * NT) & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
-        // ---- epilogue: lane = row, register 4a + i <-> column nt*32 + 8a + 4h + i; columns < N only (a quad that straddles N is
-        // stored element by element); rows past M are dropped by the range check
+#endif
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt) {
+#ifndef DN_SK_GOUTER
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(wimg + ((nt * KG + g) * 64 + lane) * 4);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[0], cur[g][0], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[1], cur[g][1], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[2], cur[g][2], acc[nt], 0, 0, 0);
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w[3], cur[g][3], acc[nt], 0, 0, 0);
+                if ((g & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // at most two weight quads in flight
+            }
+#endif
+            // ---- epilogue: lane = row, register 4a + i <-> column nt*32 + 8a + 4h + i; columns < N only (a quad that straddles N is
+            // stored element by element); rows past M are dropped by the range check
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const int n0 = nt * 32 + 8 * a + 4 * lh;
@@ -231,6 +271,7 @@ __global__ __launch_bounds__(256, WPS) void skinny_kernel(const Args p) {
                 }
                 sk_store_quad(v, rc, coff + nt * 128 + a * 32, n0, p.N);
             }
+        }
         if (!more) break;
         tile = ntile;
         if constexpr (PF) {
@@ -268,8 +309,11 @@ static hipError_t launch(const Args &a, hipStream_t st) {
 extern "C" hipError_t dn_gemm_skinny(const float *A, int64_t lda, const float *B, int64_t ldb, int transb, const float *bias, float *C,
                                      int64_t ldc, int M, int N, int K, int act, float slope, int accumulate, const float *gather,
                                      const int32_t *gidx, int64_t gs_g, int64_t gs_n, hipStream_t st) {
-    // K > 96 (the GRU gates' input gradient, K = 192): measured 54 us here against 42 us in the LDS-tiled kernel - not taken
-    if (M < 2048 || N > 192 || K > 96 || N < 1 || K < 1) return hipErrorNotSupported;
+    // K > 96: only the GRU gates' input gradient (K = 192 -> 64 columns).  Alone, the accumulating form is faster here than in the
+    // LDS-tiled kernel (46 against 57 us; 43 against 38 without accumulation), but inside the training step's graph, beside the
+    // kernels of the side streams, the step is 1 % slower with it (112.9 against 111.9 ms): off unless DAGNET_SKINNY_K192=1
+    static const bool k192 = getenv("DAGNET_SKINNY_K192") && atoi(getenv("DAGNET_SKINNY_K192")) != 0;
+    if (M < 2048 || N > 192 || N < 1 || K < 1 || K > 192 || (K > 96 && (N > 64 || !k192 || gather))) return hipErrorNotSupported;
     if ((int64_t)M * lda * 4 >= 0x7fffffffLL || (int64_t)M * ldc * 4 >= 0x7fffffffLL) return hipErrorNotSupported;     // 32-bit buffer offsets
     if (gather && (gs_g < 0 || gs_n < 0 || gs_g > 4096 || gs_n > 4096)) return hipErrorNotSupported;      // 32-bit table offsets (indices < 2^16)
     if ((lda & 3) || (ldc & 3) || lda < ((K + 3) & ~3) || ldc < ((N + 3) & ~3) || (reinterpret_cast<uintptr_t>(A) & 15) ||
@@ -290,6 +334,7 @@ extern "C" hipError_t dn_gemm_skinny(const float *A, int64_t lda, const float *B
     SK_CASE(2, 4, 4) SK_CASE(2, 8, 4) SK_CASE(2, 12, 3)
     SK_CASE(3, 4, 4) SK_CASE(3, 8, 3) SK_CASE(3, 12, 3)
     SK_CASE(6, 4, 3) SK_CASE(6, 8, 2) SK_CASE(6, 12, 2)
+    if (nt <= 2 && kg <= 24) return skinny::launch<2, 24, 3, false>(a, st);
 #undef SK_CASE
     return hipErrorNotSupported;
 }

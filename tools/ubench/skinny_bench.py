@@ -30,11 +30,22 @@ def bench(fn, reps=5):
     return best
 
 
-for (N, K, transb, acc, act) in ((64, 64, False, False, 1), (64, 64, True, False, 0), (64, 64, True, True, 0), (192, 64, False, False, 0),
-                                 (64, 192, True, False, 0), (32, 64, False, False, 0), (64, 32, False, False, 1), (92, 64, False, False, 0)):
+def pad4(n):
+    return (n + 3) & ~3
+
+
+SHAPES = ((64, 64, False, False, 1), (64, 64, True, False, 0), (64, 64, True, True, 0), (192, 64, False, False, 0),
+          (64, 192, True, False, 0), (32, 64, False, False, 0), (64, 32, False, False, 1), (92, 64, False, False, 0),
+          (90, 90, True, False, 0), (90, 90, False, False, 0), (64, 192, True, True, 0), (128, 192, True, False, 0),
+          (64, 96, True, False, 0), (64, 80, True, False, 0), (96, 64, True, False, 0), (96, 96, True, False, 0), (90, 90, True, True, 0))
+if len(sys.argv) > 2:
+    SHAPES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[2:]]
+for (N, K, transb, acc, act) in SHAPES:
+    transb, acc = bool(transb), bool(acc)
     Kk = K
-    A = [torch.randn((M, Kk), device=dev) for _ in range(NB)]
-    C = [torch.empty((M, N), device=dev) for _ in range(NB)]
+    # rows padded to 16 bytes, as StepPool hands them out in the training step
+    A = [torch.randn((M, pad4(Kk)), device=dev)[:, :Kk] for _ in range(NB)]
+    C = [torch.empty((M, pad4(N)), device=dev)[:, :N] for _ in range(NB)]
     W = torch.randn((Kk, N) if transb else (N, Kk), device=dev)
     b = torch.randn(N, device=dev)
     t = bench(lambda i: _ops.gemm(A[i], W, C[i], transb=transb, bias=None if acc else b, act=act, accumulate=acc))

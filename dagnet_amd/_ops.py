@@ -22,7 +22,7 @@ ACT_NONE, ACT_LRELU, ACT_TANH, ACT_RELU = 0, 1, 2, 3
 
 OP_EXPORTS = (
     "dagnet_op_gemm", "dagnet_op_gemm_dact", "dagnet_op_gemm_tn", "dagnet_op_gemm_tn_workspace", "dagnet_op_gemm_tn_partial", "dagnet_op_gemm_tn_finish", "dagnet_op_act_bwd", "dagnet_op_copy2d",
-    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_mlp_chain_fwd", "dagnet_op_mlp2_bwd", "dagnet_op_linear_pieces_bwd", "dagnet_op_set_fused", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats",
+    "dagnet_op_onehot_grad", "dagnet_op_softmax_fwd", "dagnet_op_softmax_bwd", "dagnet_op_gru_fwd", "dagnet_op_gru_bwd", "dagnet_op_gru_layer_fwd", "dagnet_op_mlp2_fwd", "dagnet_op_mlp_chain_fwd", "dagnet_op_mlp2_bwd", "dagnet_op_linear_pieces_bwd", "dagnet_op_set_fused", "dagnet_op_gru_pack", "dagnet_op_gru_pack_floats", "dagnet_op_gru_pack_bwd", "dagnet_op_gru_pack_bwd_floats", "dagnet_op_gru_layer_bwd",
     "dagnet_op_vae_fwd", "dagnet_op_vae_bwd", "dagnet_op_nll_fwd", "dagnet_op_nll_bwd", "dagnet_op_ce_fwd", "dagnet_op_ce_bwd", "dagnet_op_softmax_ce_bwd",
     "dagnet_op_sum", "dagnet_op_col_workspace", "dagnet_op_colsum", "dagnet_op_colsum_static", "dagnet_op_bn_fwd", "dagnet_op_bn_bwd",
     "dagnet_op_bn_moments", "dagnet_op_bn_merge", "dagnet_op_bn_apply", "dagnet_op_bn_bwd_sums", "dagnet_op_bn_bwd_apply",
@@ -64,6 +64,10 @@ def _lib():
         lib.dagnet_op_gru_pack.argtypes = [i32, i32, i32, vp, i64, vp, vp, i64, vp, vp, vp]
         lib.dagnet_op_gru_pack_floats.argtypes = [i32, i32, i32]
         lib.dagnet_op_gru_pack_floats.restype = i64
+        lib.dagnet_op_gru_pack_bwd.argtypes = [i32, i32, i32, vp, i64, vp, i64, vp, vp]
+        lib.dagnet_op_gru_pack_bwd_floats.argtypes = [i32, i32, i32]
+        lib.dagnet_op_gru_pack_bwd_floats.restype = i64
+        lib.dagnet_op_gru_layer_bwd.argtypes = [i64, i32, i32, i32, vp, i64, vp, vp, vp, i64, vp, vp, vp, vp, i64, i32, vp, i64, i32, vp, i64, i32, vp]
         lib.dagnet_op_vae_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
         lib.dagnet_op_vae_bwd.argtypes = [i64, i32, vp, vp, vp, vp, vp, vp, vp, f32, vp, vp, vp, vp, vp]
         lib.dagnet_op_nll_fwd.argtypes = [i64, i32, vp, vp, vp, vp, vp]
@@ -571,6 +575,8 @@ class LinearFn(torch.autograd.Function):
                 db = torch.empty(N, dtype=torch.float32, device=y.device)
                 colsum(dpre, db)
         for i, (x, c0) in enumerate(zip(xs, cols)):
+            if getattr(ctx, "dx_done", False):      # the consumer's backward kernel produced the input gradients (GruLayerFn)
+                break
             if ctx.needs_input_grad[8 + i] and i != fuse_at:
                 gacc = ctx.gaccs[i]
                 if gacc is not None:            # a fan-out input (FanoutFn): add into the shared gradient buffer of the tensor
@@ -925,9 +931,12 @@ class GruLayerFn(torch.autograd.Function):
     products' input and weight gradients) - exactly as in the unfused form."""
 
     @staticmethod
-    def forward(ctx, gi, gh, h, Wih, bih, Whh, bhh, pack, *xs):
+    def forward(ctx, gi, gh, h, Wih, bih, Whh, bhh, pack, packb, *xs):
         M, R = h.shape
         ctx.slot = POOL.site()
+        ctx.packb = packb
+        ctx.widths = [x.shape[1] for x in xs]
+        ctx.gaccs = [_gacc_of(h)] + [_gacc_of(x) for x in xs]       # fan-out aliases among (h, *xs): shared gradient buffers
         hn = POOL.at(ctx.slot, "hn", (M, R), h)
         gates = POOL.at(ctx.slot, "gates", (M, 3 * R), h)
         (x0, ldx0) = _m(xs[0], "x0")
@@ -938,11 +947,48 @@ class GruLayerFn(torch.autograd.Function):
         _check(_lib().dagnet_op_gru_layer_fwd(M, R, x0, ldx0, xs[0].shape[1], x1, ldx1, xs[1].shape[1] if len(xs) > 1 else 0, hp, ldh,
                                               wi, ldwi, _p(bih), wh, ldwh, _p(bhh), _p(gi), _p(gh), _p(hn), _p(gates), _p(pack), _stream(h.device)))
         ctx.save_for_backward(gates, gh, h)
-        ctx.n_extra = 5 + len(xs)
+        ctx.n_extra = 6 + len(xs)
         return hn
 
     @staticmethod
     def backward(ctx, dhn):
+        """One kernel from dh' to the gate gradients AND the input gradients of both products (dagnet_op_gru_layer_bwd); the two
+        LinearFn nodes then only record their weight-gradient operands (ctx.dx_done).  Without a fused kernel for the shape:
+        the gate-gradient kernel here, the products in the LinearFn nodes."""
+        nodes = getattr(ctx, "lin_nodes", None)
+        if ctx.packb is not None and nodes is not None and dhn is not None:
+            gates, gh, h = ctx.saved_tensors
+            M, R = h.shape
+            dhn = _rows(dhn)
+            dgi, dgh = POOL.at(ctx.slot, "dgi", (M, 3 * R), h), POOL.at(ctx.slot, "dgh", (M, 3 * R), h)
+            want = [ctx.needs_input_grad[2]] + [ctx.needs_input_grad[9 + i] for i in range(len(ctx.widths))]
+            dst, ret = [], []
+            for j, (w, gacc) in enumerate(zip(want, ctx.gaccs)):
+                if not w:
+                    dst.append((None, 0, 0))
+                    ret.append(None)
+                elif gacc is not None:
+                    buf = gacc.buffer(h)                 # every piece is [M, R] here
+                    dst.append((_p(buf), buf.stride(0), int(gacc.started)))
+                    ret.append(None)
+                else:
+                    buf = POOL.at(ctx.slot, "dh" if j == 0 else "dx%d" % (j - 1), (M, R), h)
+                    dst.append((_p(buf), buf.stride(0), 0))
+                    ret.append(buf)
+            while len(dst) < 3:
+                dst.append((None, 0, 0))
+            (pd, ldd), (ph, ldh) = _m(dhn, "dhn"), _m(h, "h")
+            K1 = ctx.widths[1] if len(ctx.widths) > 1 else 0
+            rc = _lib().dagnet_op_gru_layer_bwd(M, R, ctx.widths[0], K1, pd, ldd, _p(gates), _p(gh), ph, ldh, _p(ctx.packb), _p(dgi), _p(dgh),
+                                                *dst[1], *dst[2], *dst[0], _stream(h.device))
+            if rc != 1:
+                _check(rc)
+                for j, (w, gacc) in enumerate(zip(want, ctx.gaccs)):
+                    if w and gacc is not None:
+                        gacc.done()
+                for nd in nodes:
+                    nd.dx_done = True
+                return (dgi, dgh, ret[0], None, None, None, None, None, None, *ret[1:])
         return (*GruCellFn.backward(ctx, dhn), *([None] * ctx.n_extra))
 
 
@@ -1493,7 +1539,12 @@ def gru_packs(rnn: torch.nn.GRU, widths):
         pack = POOL.at(POOL.site(), "grupack", (n,), Wih)
         (wi, ldwi), (wh, ldwh) = _m(Wih, "W_ih"), _m(Whh, "W_hh")
         _check(lib.dagnet_op_gru_pack(R, w[0], w[1] if len(w) > 1 else 0, wi, ldwi, _p(bih), wh, ldwh, _p(bhh), _p(pack), _stream(Wih.device)))
-        out.append(pack)
+        packb = None
+        nb = lib.dagnet_op_gru_pack_bwd_floats(R, w[0], w[1] if len(w) > 1 else 0) if torch.is_grad_enabled() else 0
+        if nb > 0:        # the transposed images of the layer's backward kernel (GruLayerFn.backward)
+            packb = POOL.at(POOL.site(), "grupackb", (nb,), Wih)
+            _check(lib.dagnet_op_gru_pack_bwd(R, w[0], w[1] if len(w) > 1 else 0, wi, ldwi, wh, ldwh, _p(packb), _stream(Wih.device)))
+        out.append((pack, packb))
     return out
 
 
@@ -1513,7 +1564,10 @@ def gru_step(rnn: torch.nn.GRU, xs, cols, h_layers, packs=None):
                 gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, 0, h_layers[l])
             finally:
                 _LAZY_LINEAR = False
-            hn = GruLayerFn.apply(gi, gh, h_layers[l], Wih, bih, Whh, bhh, packs[l] if packs else None, *pieces)
+            pk, pkb = (packs[l] if packs and packs[l] is not None else (None, None))
+            hn = GruLayerFn.apply(gi, gh, h_layers[l], Wih, bih, Whh, bhh, pk, pkb, *pieces)
+            if hn.grad_fn is not None and gi.grad_fn is not None and gh.grad_fn is not None:
+                hn.grad_fn.lin_nodes = (gi.grad_fn, gh.grad_fn)
         else:
             gi = LinearFn.apply(Wih, bih, ACT_NONE, 0.0, pcols, None, 0, 0, *pieces)
             gh = LinearFn.apply(Whh, bhh, ACT_NONE, 0.0, (0,), None, 0, 0, h_layers[l])

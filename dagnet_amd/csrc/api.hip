@@ -1845,6 +1845,41 @@ extern "C" int dagnet_op_gru_layer_fwd(int64_t M, int32_t R, const float *x0, in
     HIP_TRY(dn_t_gru_fwd(M, R, gi, gh, h, hn, gates, OP_ST));
     return DAGNET_OK;
 }
+extern "C" int64_t dn_gru_pack_bwd_floats(int npieces);
+extern "C" hipError_t dn_gru_pack_bwd(int R, int npieces, const float *Wih, int64_t ldwih, const float *Whh, int64_t ldwhh, float *out,
+                                      hipStream_t st);
+extern "C" hipError_t dn_gru_fused_bwd(int64_t M, int R, int npieces, const float *dhn, int64_t lddhn, const float *gates, int64_t ldg,
+                                       const float *gh, int64_t ldgh, const float *h, int64_t ldh, const float *pack, float *dgi,
+                                       int64_t lddgi, float *dgh, int64_t lddgh, float *dx0, int64_t lddx0, int acc0, float *dx1,
+                                       int64_t lddx1, int acc1, float *dh, int64_t lddh, int acch, hipStream_t st);
+// -> floats of the packed image dagnet_op_gru_layer_bwd takes (0: this shape has no fused backward kernel)
+extern "C" int64_t dagnet_op_gru_pack_bwd_floats(int32_t R, int32_t K0, int32_t K1) {
+    return (R == 64 && K0 == 64 && (K1 == 0 || K1 == 64)) ? dn_gru_pack_bwd_floats(K1 ? 2 : 1) : 0;
+}
+extern "C" int dagnet_op_gru_pack_bwd(int32_t R, int32_t K0, int32_t K1, const float *Wih, int64_t ldwih, const float *Whh, int64_t ldwhh,
+                                      float *out, void *stream) {
+    OP_NEED(dagnet_op_gru_pack_bwd_floats(R, K0, K1) > 0 && Wih && Whh && out, "no fused GRU backward kernel for this shape");
+    HIP_TRY(dn_gru_pack_bwd(R, K1 ? 2 : 1, Wih, ldwih, Whh, ldwhh, out, OP_ST));
+    return DAGNET_OK;
+}
+// Backward of one GRU layer step in one kernel (csrc/gru_fused.hip gru_fused_bwd_kernel): gate gradients dgi / dgh [M,3R] (written
+// for the weight-gradient products) and the input gradients dx0 / dx1 (+)= dgi W_ih[:, piece], dh (+)= dhn z + dgh W_hh (NULL: not
+// wanted).  -> 1 (nothing written) when the shape has no fused kernel or bit 0 of dagnet_op_set_fused is cleared.
+extern "C" int dagnet_op_gru_layer_bwd(int64_t M, int32_t R, int32_t K0, int32_t K1, const float *dhn, int64_t lddhn, const float *gates,
+                                       const float *gh, const float *h, int64_t ldh, const float *pack, float *dgi, float *dgh, float *dx0,
+                                       int64_t lddx0, int32_t acc0, float *dx1, int64_t lddx1, int32_t acc1, float *dh, int64_t lddh,
+                                       int32_t acch, void *stream) {
+    OP_NEED(M >= 0 && R >= 1 && M < 0x7fffffffLL, "bad argument");
+    static const bool off = getenv("DAGNET_NO_GRU_BWD_FUSED") != nullptr;
+    if (off || !(fused_mask() & 1) || !pack || !(K0 == 64 && (K1 == 0 || K1 == 64))) return 1;
+    if (M == 0) return DAGNET_OK;
+    OP_NEED(dhn && gates && gh && h && dgi && dgh, "null operand");
+    const hipError_t e = dn_gru_fused_bwd(M, R, K1 ? 2 : 1, dhn, lddhn, gates, 3 * R, gh, 3 * R, h, ldh, pack, dgi, 3 * R, dgh, 3 * R, dx0,
+                                          lddx0, acc0, dx1, lddx1, acc1, dh, lddh, acch, OP_ST);
+    if (e == hipErrorNotSupported) return 1;
+    HIP_TRY(e);
+    return DAGNET_OK;
+}
 // y1 = act1([x_0 | x_1 | x_2 | one-hot(gidx)] W1^T + b1) [M,N1], y2 = act2(y1 W2^T + b2) [M,N2]; piece s sits at columns cols[s] of W1,
 // the one-hot block at gcol.  One kernel for the 64 / 64 blocks of the models (csrc/mlp_fused.hip), layer by layer otherwise.
 extern "C" int dagnet_op_mlp2_fwd(int64_t M, int32_t npieces, const float *const *x, const int64_t *ldx, const int32_t *K,

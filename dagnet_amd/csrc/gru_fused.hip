@@ -221,6 +221,203 @@ static hipError_t launch(const Args &a, hipStream_t st) {
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Backward of the same layer step as ONE kernel.  Layer by layer it is the gate-gradient kernel (train_ops.hip gru_bwd_kernel:
+// reads dh', the gates, W_hn h + b_hn and h, writes the [M,192] gate gradients of both products) followed by two or three
+// K = 192 input-gradient products that read those matrices back (gemm_f32.hip, ~55 us each at 81 920 rows): ~590 MB and four
+// launches per layer step.  Here a wave takes a 32-row tile from dh' to the input gradients: the gate gradients are computed in
+// the registers that are the MFMA operands of the two products (lane = row, k = 8 g + 4 lh + i as in the forward kernel), written
+// out once for the deferred weight-gradient products, and multiplied with W_ih / W_hh images that stay in LDS:
+//     dn = dh' (1 - z), dz = dh' (h - n);  dpn = dn (1 - n^2), dpr = dpn ghn r (1 - r), dpz = dz z (1 - z)
+//     dgi = [dpr | dpz | dpn],  dgh = [dpr | dpz | dpn r];  dx_p (+)= dgi W_ih[:, 64 p : 64 p + 64],  dh (+)= dh' z + dgh W_hh
+// ---------------------------------------------------------------------------------------------------------------------------
+struct BArgs {
+    const float *dhn; int64_t lddhn;   // [M, 64]  gradient of h'
+    const float *gates; int64_t ldg;   // [M, 192] r | z | n
+    const float *gh; int64_t ldgh;     // [M, 192] columns 128..191 = W_hn h + b_hn
+    const float *h; int64_t ldh;       // [M, 64]
+    const float *pack;                 // dn_gru_pack_bwd image
+    float *dgi; int64_t lddgi;         // [M, 192]
+    float *dgh; int64_t lddgh;         // [M, 192]
+    float *dx0; int64_t lddx0; int acc0;      // [M, 64] (null: not wanted)
+    float *dx1; int64_t lddx1; int acc1;
+    float *dh; int64_t lddh; int acch;
+    int M;
+};
+
+constexpr int KGB = 24;                // k-groups of 8 over the 192 gate columns
+
+// image: wi [2 NP][24][64][4] | wh [2][24][64][4]; quad (nt, g, l) = W[8 g + 4 (l >> 5) + 0..3][32 nt + (l & 31)]
+template <int NP>
+__global__ __launch_bounds__(256) void gru_pack_bwd_kernel(float *out, const float *Wih, int64_t ldwih, const float *Whh, int64_t ldwhh) {
+    const int tid = (int)(blockIdx.x * blockDim.x + threadIdx.x), nthr = (int)(gridDim.x * blockDim.x);
+    constexpr int NI = 2 * NP * KGB * 64, NH = 2 * KGB * 64;
+    for (int e = tid; e < NI + NH; e += nthr) {
+        const bool hid = e >= NI;
+        const int q = hid ? e - NI : e;
+        const int l = q & 63, g = (q >> 6) % KGB, nt = (q >> 6) / KGB;
+        const float *W = hid ? Whh : Wih;
+        const int64_t ld = hid ? ldwhh : ldwih;
+        const int k = 8 * g + 4 * (l >> 5), n = 32 * nt + (l & 31);
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = W[(int64_t)(k + i) * ld + n];
+        *reinterpret_cast<f32x4 *>(out + (int64_t)e * 4) = v;
+    }
+}
+
+template <int NP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 1) void gru_fused_bwd_kernel(const BArgs p) {
+    constexpr int NTHR = 64 * WAVES;
+    constexpr int NTX = 2 * NP;
+    extern __shared__ float lds[];
+    float *wi = lds, *wh = lds + NTX * KGB * 256;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
+    {
+        constexpr int NQ = (NTX * KGB * 256 + 2 * KGB * 256) / 4;
+        for (int e = tid; e < NQ; e += NTHR)
+            *reinterpret_cast<f32x4 *>(lds + e * 4) = *reinterpret_cast<const f32x4 *>(p.pack + e * 4);
+    }
+    __syncthreads();
+    const int n_tiles = (p.M + 31) >> 5;
+    const int stride = (int)gridDim.x * WAVES;
+    // tiles are dealt round-robin over the workgroups first, so that a last partial round spreads over all CUs
+    int tile = (int)blockIdx.x + (int)gridDim.x * wave;
+    if (tile >= n_tiles) return;
+    const i32x4 rd = make_rsrc(p.dhn, (int64_t)p.M * p.lddhn * 4), rg = make_rsrc(p.gates, (int64_t)p.M * p.ldg * 4);
+    const i32x4 rgh = make_rsrc(p.gh, (int64_t)p.M * p.ldgh * 4), rh = make_rsrc(p.h, (int64_t)p.M * p.ldh * 4);
+    const i32x4 rdgi = make_rsrc(p.dgi, (int64_t)p.M * p.lddgi * 4), rdgh = make_rsrc(p.dgh, (int64_t)p.M * p.lddgh * 4);
+    const i32x4 rx0 = make_rsrc(p.dx0 ? p.dx0 : p.dgi, p.dx0 ? (int64_t)p.M * p.lddx0 * 4 : 0);
+    const i32x4 rx1 = make_rsrc(p.dx1 ? p.dx1 : p.dgi, p.dx1 ? (int64_t)p.M * p.lddx1 * 4 : 0);
+    const i32x4 rdh = make_rsrc(p.dh ? p.dh : p.dgi, p.dh ? (int64_t)p.M * p.lddh * 4 : 0);
+    const int ldd4 = (int)p.lddhn * 4, ldg4 = (int)p.ldg * 4, ldgh4 = (int)p.ldgh * 4, ldh4 = (int)p.ldh * 4;
+    const int lddgi4 = (int)p.lddgi * 4, lddgh4 = (int)p.lddgh * 4;
+    const int lddx04 = (int)p.lddx0 * 4, lddx14 = (int)p.lddx1 * 4, lddh4 = (int)p.lddh * 4;
+
+    for (; tile < n_tiles; tile += stride) {
+        const int row = tile * 32 + lr;          // rows past M: the range check returns 0 / drops the store
+        // ---- gate gradients, two k-groups at a time (12 quads in flight; the other wave of the SIMD covers their latency)
+        f32x4 gr[8], gz[8], gn[8], gnr[8], dhz[8];
+#pragma unroll
+        for (int gp = 0; gp < 4; ++gp) {
+            f32x4 d[2], hq[2], r[2], z[2], n[2], gq[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int off = 16 * lh + (2 * gp + u) * 32;
+                d[u] = gf_load4(rd, row * ldd4 + off, 0, 0);
+                hq[u] = gf_load4(rh, row * ldh4 + off, 0, 0);
+                r[u] = gf_load4(rg, row * ldg4 + off, 0, 0);
+                z[u] = gf_load4(rg, row * ldg4 + 256 + off, 0, 0);
+                n[u] = gf_load4(rg, row * ldg4 + 512 + off, 0, 0);
+                gq[u] = gf_load4(rgh, row * ldgh4 + 512 + off, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int gj = 2 * gp + u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float dd = d[u][i], rr = r[u][i], zz = z[u][i], nn = n[u][i];
+                    const float dn = dd * (1.0f - zz), dz = dd * (hq[u][i] - nn);
+                    const float dpn = dn * (1.0f - nn * nn);
+                    gr[gj][i] = dpn * gq[u][i] * rr * (1.0f - rr);
+                    gz[gj][i] = dz * zz * (1.0f - zz);
+                    gn[gj][i] = dpn;
+                    gnr[gj][i] = dpn * rr;
+                    dhz[gj][i] = dd * zz;
+                }
+                const int off = 16 * lh + gj * 32;
+                gf_store4(gr[gj], rdgi, row * lddgi4 + off, 0, 0);
+                gf_store4(gz[gj], rdgi, row * lddgi4 + 256 + off, 0, 0);
+                gf_store4(gn[gj], rdgi, row * lddgi4 + 512 + off, 0, 0);
+                gf_store4(gr[gj], rdgh, row * lddgh4 + off, 0, 0);
+                gf_store4(gz[gj], rdgh, row * lddgh4 + 256 + off, 0, 0);
+                gf_store4(gnr[gj], rdgh, row * lddgh4 + 512 + off, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- one pair of 32-column output tiles of a product: acc[t] = W image tiles (nt0, nt0 + 1) x gate gradients.  The two
+        // accumulators alternate (four MFMAs in a row on one accumulator wait for each other); the weight quads of group g + 1 are
+        // read from LDS while group g multiplies.
+        auto product = [&](f32x16 (&acc)[2], const float *img, int nt0, bool hidden) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+            f32x4 w0[2], w1[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) w0[t] = *reinterpret_cast<const f32x4 *>(img + (((nt0 + t) * KGB + 0) * 64 + lane) * 4);
+#pragma unroll
+            for (int g = 0; g < KGB; ++g) {
+                f32x4 (&wc)[2] = (g & 1) ? w1 : w0;
+                f32x4 (&wn)[2] = (g & 1) ? w0 : w1;
+                if (g + 1 < KGB) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) wn[t] = *reinterpret_cast<const f32x4 *>(img + (((nt0 + t) * KGB + g + 1) * 64 + lane) * 4);
+                }
+                const f32x4 b = g < 8 ? gr[g & 7] : g < 16 ? gz[g & 7] : (hidden ? gnr[g & 7] : gn[g & 7]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[0][i], b[i], acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[1][i], b[i], acc[1], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        // lane = row, register 4 a + i of tile t <-> column 32 t + 8 a + 4 lh + i of the 64-wide destination
+        auto put = [&](const f32x16 (&acc)[2], i32x4 rsrc, int ld4, int accumulate, const f32x4 *extra) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const int voff = row * ld4 + (32 * t + 8 * a + 4 * lh) * 4;
+                    f32x4 v;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = acc[t][4 * a + i];
+                    if (extra) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += extra[4 * t + a][i];
+                    }
+                    if (accumulate) {
+                        const f32x4 c = gf_load4(rsrc, voff, 0, 0);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] += c[i];
+                    }
+                    gf_store4(v, rsrc, voff, 0, 0);
+                }
+        };
+        f32x16 acc[2];
+        if (p.dh) {              // dh = dh' z + dgh W_hh: column 32 t + 8 a + 4 lh + i is element i of this lane's quad gj = 4 t + a
+            product(acc, wh, 0, true);
+            put(acc, rdh, lddh4, p.acch, dhz);
+        }
+        if (p.dx0) {
+            product(acc, wi, 0, false);
+            put(acc, rx0, lddx04, p.acc0, nullptr);
+        }
+        if constexpr (NP == 2) {
+            if (p.dx1) {
+                product(acc, wi, 2, false);
+                put(acc, rx1, lddx14, p.acc1, nullptr);
+            }
+        }
+    }
+}
+
+template <int NP, int WAVES>
+static hipError_t launch_bwd(const BArgs &a, hipStream_t st) {
+    const size_t lds = ((size_t)2 * NP * KGB * 256 + 2 * KGB * 256) * sizeof(float);
+    const int64_t tiles = ((int64_t)a.M + 31) / 32;
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1)
+        cus = 256;
+    const int64_t blocks = std::min<int64_t>(tiles, cus);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(gru_fused_bwd_kernel<NP, WAVES>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((gru_fused_bwd_kernel<NP, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, st, a);
+    return hipGetLastError();
+}
+
 }  // namespace gruf
 
 // -> hipErrorNotSupported when the shapes or alignments are not the ones above (the caller then runs the layer as products + cell).
@@ -257,4 +454,38 @@ extern "C" hipError_t dn_gru_pack(int R, int npieces, const float *Wih, int64_t 
     if (npieces == 2) hipLaunchKernelGGL(gruf::gru_pack_kernel<16>, dim3(36), dim3(256), 0, st, out, Wih, ldwih, Whh, ldwhh, bih, bhh);
     else hipLaunchKernelGGL(gruf::gru_pack_kernel<8>, dim3(24), dim3(256), 0, st, out, Wih, ldwih, Whh, ldwhh, bih, bhh);
     return hipGetLastError();
+}
+
+// ---- backward of the layer step (gru_fused_bwd_kernel).  -> hipErrorNotSupported when the shape is not the fused one.
+extern "C" int64_t dn_gru_pack_bwd_floats(int npieces) { return (int64_t)2 * npieces * gruf::KGB * 256 + 2 * gruf::KGB * 256; }
+extern "C" hipError_t dn_gru_pack_bwd(int R, int npieces, const float *Wih, int64_t ldwih, const float *Whh, int64_t ldwhh, float *out,
+                                      hipStream_t st) {
+    if (R != gruf::R || npieces < 1 || npieces > 2 || !Wih || !Whh || !out || ldwih < 64 * npieces || ldwhh < 64 ||
+        (reinterpret_cast<uintptr_t>(out) & 15))
+        return hipErrorNotSupported;
+    if (npieces == 2) hipLaunchKernelGGL(gruf::gru_pack_bwd_kernel<2>, dim3(36), dim3(256), 0, st, out, Wih, ldwih, Whh, ldwhh);
+    else hipLaunchKernelGGL(gruf::gru_pack_bwd_kernel<1>, dim3(24), dim3(256), 0, st, out, Wih, ldwih, Whh, ldwhh);
+    return hipGetLastError();
+}
+extern "C" hipError_t dn_gru_fused_bwd(int64_t M, int R, int npieces, const float *dhn, int64_t lddhn, const float *gates, int64_t ldg,
+                                       const float *gh, int64_t ldgh, const float *h, int64_t ldh, const float *pack, float *dgi,
+                                       int64_t lddgi, float *dgh, int64_t lddgh, float *dx0, int64_t lddx0, int acc0, float *dx1,
+                                       int64_t lddx1, int acc1, float *dh, int64_t lddh, int acch, hipStream_t st) {
+    if (R != gruf::R || npieces < 1 || npieces > 2 || M < 2048 || !pack) return hipErrorNotSupported;
+    if (npieces == 1 && dx1) return hipErrorNotSupported;
+    const int64_t lim = 0x7fffffffLL;
+    const int64_t lds[] = {lddhn, ldg, ldgh, ldh, lddgi, lddgh, dx0 ? lddx0 : 64, dx1 ? lddx1 : 64, dh ? lddh : 64};
+    int64_t ldmax = 0;
+    for (int64_t ld : lds) {
+        if ((ld & 3) || ld < 64) return hipErrorNotSupported;
+        ldmax = std::max(ldmax, ld);
+    }
+    if (ldg < 192 || ldgh < 192 || lddgi < 192 || lddgh < 192 || M * ldmax * 4 >= lim) return hipErrorNotSupported;
+    const void *ptrs[] = {dhn, gates, gh, h, pack, dgi, dgh, dx0 ? dx0 : dgi, dx1 ? dx1 : dgi, dh ? dh : dgi};
+    for (const void *q : ptrs)
+        if (!q || (reinterpret_cast<uintptr_t>(q) & 15)) return hipErrorNotSupported;
+    gruf::BArgs a{dhn, lddhn, gates, ldg, gh, ldgh, h, ldh, pack, dgi, lddgi, dgh, lddgh, dx0, lddx0, acc0, dx1, lddx1, acc1, dh, lddh, acch, (int)M};
+    static const int waves = getenv("DAGNET_GRU_BWD_WAVES") ? atoi(getenv("DAGNET_GRU_BWD_WAVES")) : 8;
+    if (npieces == 2) return waves == 4 ? gruf::launch_bwd<2, 4>(a, st) : gruf::launch_bwd<2, 8>(a, st);
+    return waves == 4 ? gruf::launch_bwd<1, 4>(a, st) : gruf::launch_bwd<1, 8>(a, st);
 }

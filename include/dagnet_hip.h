@@ -303,6 +303,20 @@ int dagnet_op_gru_pack(int32_t R, int32_t K0, int32_t K1, const float *Wih, int6
                        int64_t ldwhh, const float *bhh, float *out, void *stream);
 int dagnet_op_gru_bwd(int64_t M, int32_t R, const float *dhn, const float *gates, const float *gh, const float *h, float *dgi,
                       float *dgh, float *dh, void *stream);
+/* Replaces: autograd's backward of that layer step (models/dagnet/model.py:109-110,:186: nn.GRU's gate gradients and the input
+ * gradients of its two products) as ONE kernel for rnn_dim 64 with 64-wide pieces and >= 2048 rows: from dhn [M,R] (gradient of
+ * h'), the saved gates [M,3R], gh [M,3R] (columns 2R..3R) and h to the gate gradients dgi, dgh [M,3R] (contiguous; the
+ * weight-gradient products read them) and dx0 / dx1 (+)= dgi W_ih[:, piece], dh (+)= dhn z + dgh W_hh (NULL: not wanted; acc: add
+ * to what is there).  pack: dagnet_op_gru_pack_bwd_floats(R, K0, K1) floats written by dagnet_op_gru_pack_bwd, valid until the
+ * weights change.  Returns 1 (nothing written) when the shape has no fused kernel, without a pack, or with bit 0 of
+ * dagnet_op_set_fused cleared / DAGNET_NO_GRU_BWD_FUSED set: the caller then runs dagnet_op_gru_bwd and the products. */
+int64_t dagnet_op_gru_pack_bwd_floats(int32_t R, int32_t K0, int32_t K1);
+int dagnet_op_gru_pack_bwd(int32_t R, int32_t K0, int32_t K1, const float *Wih, int64_t ldwih, const float *Whh, int64_t ldwhh,
+                           float *out, void *stream);
+int dagnet_op_gru_layer_bwd(int64_t M, int32_t R, int32_t K0, int32_t K1, const float *dhn, int64_t lddhn, const float *gates,
+                            const float *gh, const float *h, int64_t ldh, const float *pack, float *dgi, float *dgh, float *dx0,
+                            int64_t lddx0, int32_t acc0, float *dx1, int64_t lddx1, int32_t acc1, float *dh, int64_t lddh, int32_t acch,
+                            void *stream);
 /* Replaces: _reparameterize + _kld (models/dagnet/model.py:118-128): z = eps exp(logvar_e / 2) + mean_e, kld_row[m] =
  * per-row KLD (the caller takes the mean with dagnet_op_sum); backward from dz and the scalar gradient g_kld[0] * scale. */
 int dagnet_op_vae_fwd(int64_t M, int32_t Z, const float *mu_e, const float *lv_e, const float *mu_p, const float *lv_p,

@@ -308,6 +308,62 @@ def test_gru_layer_matches_torch(M, pieces):
     torch.testing.assert_close(gh[:, 2 * R:].double(), b[:, 2 * R:], **tol)
 
 
+@pytest.mark.parametrize("M,pieces,acc", [(4100, (64, 64), (0, 0, 0)), (2500, (64,), (1, 0, 1)), (40960, (64, 64), (1, 1, 0)), (3000, (64, 64), None),
+                                          (100, (64, 64), (0, 0, 0))])
+def test_gru_layer_backward_matches_the_equations(M, pieces, acc):
+    """dagnet_op_gru_layer_bwd (one kernel from dh' to the gate gradients and the input gradients of both products) against the GRU
+    backward equations in fp64, with and without accumulation into the destinations; acc None: no destination wanted (gate
+    gradients only); M < 2048: no fused kernel (returns 1, nothing written)."""
+    import ctypes
+    g = torch.Generator().manual_seed(3 * M + sum(pieces))
+    R, K = 64, sum(pieces)
+    rnd = lambda *shape: torch.randn(shape, generator=g).to(DEV)  # noqa: E731
+    h, dhn = rnd(M, R), rnd(M, R)
+    gates = torch.cat([torch.sigmoid(rnd(M, 2 * R)), torch.tanh(rnd(M, R))], 1).contiguous()
+    gh = torch.full((M, 3 * R), float("nan"), device=DEV)
+    gh[:, 2 * R:] = rnd(M, R)
+    Wih, Whh = (rnd(3 * R, K) / K ** 0.5), rnd(3 * R, R) / 8
+    lib = _ops._lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    k1 = pieces[1] if len(pieces) > 1 else 0
+    nb = lib.dagnet_op_gru_pack_bwd_floats(R, pieces[0], k1)
+    assert nb > 0
+    packb = torch.empty(nb, device=DEV)
+    _ops._check(lib.dagnet_op_gru_pack_bwd(R, pieces[0], k1, p(Wih), K, p(Whh), R, p(packb), st))
+    dgi = torch.full((M, 3 * R), float("nan"), device=DEV)
+    dgh = torch.full((M, 3 * R), float("nan"), device=DEV)
+    # destinations: column slices of wider buffers (row stride 68), pre-filled when accumulating
+    want = acc is not None
+    a = acc or (0, 0, 0)
+    bufs = [rnd(M, 68) for _ in range(3)]
+    before = [b.clone() for b in bufs]
+    dx = [bufs[i][:, :R] for i in range(3)]
+    rc = lib.dagnet_op_gru_layer_bwd(M, R, pieces[0], k1, p(dhn), R, p(gates), p(gh), p(h), R, p(packb), p(dgi), p(dgh),
+                                     p(dx[0]) if want else None, 68, a[0], p(dx[1]) if want and k1 else None, 68, a[1],
+                                     p(dx[2]) if want else None, 68, a[2], st)
+    if M < 2048:
+        assert rc == 1 and torch.isnan(dgi).all()
+        return
+    _ops._check(rc)
+    r, z, n = gates[:, :R].double(), gates[:, R:2 * R].double(), gates[:, 2 * R:].double()
+    d, hd, ghn = dhn.double(), h.double(), gh[:, 2 * R:].double()
+    dpn = d * (1 - z) * (1 - n * n)
+    dpr, dpz = dpn * ghn * r * (1 - r), d * (hd - n) * z * (1 - z)
+    e_dgi, e_dgh = torch.cat([dpr, dpz, dpn], 1), torch.cat([dpr, dpz, dpn * r], 1)
+    tol = dict(rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(dgi.double(), e_dgi, **tol)
+    torch.testing.assert_close(dgh.double(), e_dgh, **tol)
+    e_dx = e_dgi @ Wih.double()
+    exp = [e_dx[:, :64], e_dx[:, 64:128] if k1 else None, d * z + e_dgh @ Whh.double()]
+    for i in range(3):
+        if exp[i] is None or not want:
+            assert torch.equal(bufs[i], before[i])            # untouched
+            continue
+        torch.testing.assert_close(dx[i].double(), exp[i] + (before[i][:, :R].double() if a[i] else 0), **tol)
+        assert torch.equal(bufs[i][:, R:], before[i][:, R:])  # the padding columns belong to the caller
+
+
 @pytest.mark.parametrize("M,pieces,gather", [(4100, (2,), False), (3000, (32,), False), (2500, (16,), False), (5000, (64,), True), (4096, (64, 64), True),
                                              (2049, (64, 64), False), (3100, (2, 64, 64), True), (100, (64, 64), True), (3000, (16, 64), True),
                                              (40960, (2, 64, 64), True)])

@@ -625,6 +625,23 @@ struct Scenes {
 };
 
 #define GAT_T 64
+// Global -> LDS staging for the single-wave attention workgroups: the loads of up to U elements per lane are issued back to
+// back and only then written to LDS.  Written as `for (e) lds[e] = f(global[e])`, the compiler keeps ONE load in flight per
+// iteration (load, s_waitcnt vmcnt(0), ds_write, next load): ten serial HBM round trips for a 10 x 64 scene slab, which was
+// most of these kernels' 35 - 70 us.  load(e) must be safe for every e < total (it is called with e clamped, unconditionally,
+// so that no load sits behind a branch); store(e, v) runs for e < total only.
+struct GatV3 { float a, b, c; };
+template <int U, class V, class L, class S>
+__device__ __forceinline__ void gat_stage(int total, int tid, L load, S store) {
+    for (int e0 = tid; e0 < total; e0 += GAT_T * U) {
+        V v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = load(min(e0 + u * GAT_T, total - 1));
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (e0 + u * GAT_T < total) store(e0 + u * GAT_T, v[u]);
+    }
+}
 // e / d for 0 <= e < 2^16 with a divisor that is only known at run time (agents of the scene, head width): one v_mul_hi instead of
 // the ~35-instruction unsigned division - these kernels index everything by (row, feature) or (row, row) pairs of a flat e
 struct FastDiv {
@@ -656,11 +673,12 @@ __device__ __forceinline__ void gat_logits(int n, int F, int FP, int64_t rld, co
     }
     __syncthreads();
     const FastDiv dn(n);
-    for (int e = tid; e < n * n; e += GAT_T) {
-        const int i = dn(e), j = e - i * n;
-        const float v = s1[i] + s2[j];
-        att[e] = ablk[i * rld + j] > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
-    }
+    gat_stage<4, float>(n * n, tid, [&](int e) { const int i = dn(e); return ablk[i * rld + (e - i * n)]; },
+                        [&](int e, float adjv) {
+                            const int i = dn(e), j = e - i * n;
+                            const float v = s1[i] + s2[j];
+                            att[e] = adjv > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
+                        });
     __syncthreads();
     for (int i = tid; i < n; i += GAT_T) {
         float mx = -INFINITY;
@@ -688,14 +706,12 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_fwd_kernel(Scenes sc, const fl
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
     const FastDiv dFP(FP), dF4(F4);
-    for (int e = tid; e < 2 * FP; e += GAT_T) {                // the attention vector: read F times per row below
-        const int w = e >= FP, f = e - w * FP;
-        ah[e] = f < F ? a[(int64_t)hd * 2 * F + w * F + f] : 0.f;
-    }
-    for (int e = tid; e < n * FP; e += GAT_T) {
-        const int i = dFP(e), f = e - i * FP;
-        wh[e] = f < F ? Wh[(int64_t)(b + i) * ldw + hd * F + f] : 0.f;
-    }
+    gat_stage<4, float>(2 * FP, tid,                           // the attention vector: read F times per row below
+                        [&](int e) { const int w = e >= FP, f = min(e - w * FP, F - 1); return a[(int64_t)hd * 2 * F + w * F + f]; },
+                        [&](int e, float v) { const int w = e >= FP; ah[e] = e - w * FP < F ? v : 0.f; });
+    gat_stage<12, float>(n * FP, tid,
+                         [&](int e) { const int i = dFP(e), f = min(e - i * FP, F - 1); return Wh[(int64_t)(b + i) * ldw + hd * F + f]; },
+                         [&](int e, float v) { const int i = dFP(e); wh[e] = e - i * FP < F ? v : 0.f; });
     __syncthreads();
     gat_logits(n, F, FP, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
     const float4 *wh4 = reinterpret_cast<const float4 *>(wh);
@@ -736,23 +752,24 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_kernel(Scenes sc, const fl
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
     const FastDiv dFP(FP), dF4(F4), dn(n);
-    for (int e = tid; e < 2 * FP; e += GAT_T) {
-        const int w = e >= FP, f = e - w * FP;
-        ah[e] = f < F ? a[(int64_t)hd * 2 * F + w * F + f] : 0.f;
-    }
-    for (int e = tid; e < n * FP; e += GAT_T) {
-        const int ii = dFP(e), f = e - ii * FP;
-        float w = 0.f, g = 0.f;
-        if (f < F) {
-            const int64_t row = b + ii;
-            const int col = hd * F + f;
-            w = Wh[row * ldw + col];
-            g = dOut[row * ldd + col];
-            if (elu) { const float o = Out[row * ldo + col]; g *= o > 0.f ? 1.f : o + 1.f; }
-        }
-        wh[e] = w;
-        dO[e] = g;
-    }
+    gat_stage<4, float>(2 * FP, tid,
+                        [&](int e) { const int w = e >= FP, f = min(e - w * FP, F - 1); return a[(int64_t)hd * 2 * F + w * F + f]; },
+                        [&](int e, float v) { const int w = e >= FP; ah[e] = e - w * FP < F ? v : 0.f; });
+    gat_stage<6, GatV3>(n * FP, tid,
+                        [&](int e) {
+                            const int ii = dFP(e), f = min(e - ii * FP, F - 1);
+                            const int64_t row = b + ii;
+                            const int col = hd * F + f;
+                            return GatV3{Wh[row * ldw + col], dOut[row * ldd + col], elu ? Out[row * ldo + col] : 1.f};
+                        },
+                        [&](int e, GatV3 v) {
+                            const int ii = dFP(e);
+                            const bool in = e - ii * FP < F;
+                            float g = v.b;
+                            if (elu) g *= v.c > 0.f ? 1.f : v.c + 1.f;
+                            wh[e] = in ? v.a : 0.f;
+                            dO[e] = in ? g : 0.f;
+                        });
     __syncthreads();
     gat_logits(n, F, FP, rld, wh, ah, ablk, alpha, s1, s2, att, tid);
     const float4 *wh4 = reinterpret_cast<const float4 *>(wh), *dO4 = reinterpret_cast<const float4 *>(dO);
@@ -829,11 +846,13 @@ __device__ __forceinline__ void gat_logits_heads(int n, int H, int F, int64_t rl
         (w ? s2 : s1)[hd * n + i] = u;
     }
     __syncthreads();
-    for (int e = tid; e < H * nn; e += GAT_T) {
-        const int hd = dnn(e), ij = e - hd * nn, i = dn(ij), j = ij - i * n;
-        const float v = s1[hd * n + i] + s2[hd * n + j];
-        att[e] = ablk[i * rld + j] > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
-    }
+    gat_stage<8, float>(H * nn, tid,
+                        [&](int e) { const int hd = dnn(e), ij = e - hd * nn, i = dn(ij); return ablk[i * rld + (ij - i * n)]; },
+                        [&](int e, float adjv) {
+                            const int hd = dnn(e), ij = e - hd * nn, i = dn(ij), j = ij - i * n;
+                            const float v = s1[hd * n + i] + s2[hd * n + j];
+                            att[e] = adjv > 0.f ? fmaxf(v, v * alpha) : -INFINITY;
+                        });
     __syncthreads();
     for (int e = tid; e < H * n; e += GAT_T) {
         float *row = att + (int64_t)e * n;          // e = hd * n + i
@@ -862,11 +881,9 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_fwd_heads_kernel(Scenes sc, co
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
     const FastDiv dHF(HF), dF(F);
-    for (int e = tid; e < H * 2 * F; e += GAT_T) as[e] = a[e];          // the heads' attention vectors
-    for (int e = tid; e < n * HF; e += GAT_T) {
-        const int i = dHF(e);
-        wh[e] = Wh[(int64_t)(b + i) * ldw + (e - i * HF)];
-    }
+    gat_stage<2, float>(H * 2 * F, tid, [&](int e) { return a[e]; }, [&](int e, float v) { as[e] = v; });      // the heads' attention vectors
+    gat_stage<8, float>(n * HF, tid, [&](int e) { const int i = dHF(e); return Wh[(int64_t)(b + i) * ldw + (e - i * HF)]; },
+                        [&](int e, float v) { wh[e] = v; });
     __syncthreads();
     gat_logits_heads(n, H, F, rld, wh, as, ablk, alpha, s1, s2, att, tid);
     for (int e = tid; e < n * HF; e += GAT_T) {
@@ -894,15 +911,19 @@ __global__ __launch_bounds__(GAT_T) void gat_attn_bwd_heads_kernel(Scenes sc, co
     const int64_t rld = sc.ld ? sc.ld : n;
     const int tid = threadIdx.x;
     const FastDiv dHF(HF), dF(F), dnn(nn), dn(n), d2F(2 * F);
-    for (int e = tid; e < H * 2 * F; e += GAT_T) as[e] = a[e];
-    for (int e = tid; e < n * HF; e += GAT_T) {
-        const int i = dHF(e), c = e - i * HF;
-        const int64_t row = b + i;
-        wh[e] = Wh[row * ldw + c];
-        float g = dOut[row * ldd + c];
-        if (elu) { const float o = Out[row * ldo + c]; g *= o > 0.f ? 1.f : o + 1.f; }
-        dO[e] = g;
-    }
+    gat_stage<2, float>(H * 2 * F, tid, [&](int e) { return a[e]; }, [&](int e, float v) { as[e] = v; });
+    gat_stage<6, GatV3>(n * HF, tid,
+                        [&](int e) {
+                            const int i = dHF(e), c = e - i * HF;
+                            const int64_t row = b + i;
+                            return GatV3{Wh[row * ldw + c], dOut[row * ldd + c], elu ? Out[row * ldo + c] : 1.f};
+                        },
+                        [&](int e, GatV3 v) {
+                            float g = v.b;
+                            if (elu) g *= v.c > 0.f ? 1.f : v.c + 1.f;
+                            wh[e] = v.a;
+                            dO[e] = g;
+                        });
     __syncthreads();
     gat_logits_heads(n, H, F, rld, wh, as, ablk, alpha, s1, s2, att, tid);
     // d att_ij = dO_i . Wh_j (per head)

@@ -42,6 +42,32 @@ __device__ __forceinline__ float act_apply(int act, float v, float slope) {
     return v;
 }
 
+// A weight image of COUNT quads, a thread taking quads tid, tid + 256, ...: ALL of the thread's loads are issued before its LDS
+// writes.  Written as `for (e = tid; e < n; e += 256) lds[e] = f(W[..])` the loops below compiled to one load in flight per
+// iteration (load, s_waitcnt vmcnt(0), ds_write): 16 to 64 serial L2 round trips in front of every workgroup's first tile.
+// load(q) is called unconditionally with q clamped to the image.
+template <int COUNT, class L>
+__device__ __forceinline__ void stage_quads(float *dst, int tid, L load) {
+    constexpr int IT = (COUNT + 255) / 256;
+    f32x4 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) v[it] = load(min(tid + 256 * it, COUNT - 1));
+#pragma unroll
+    for (int it = 0; it < IT; ++it)
+        if (COUNT % 256 == 0 || tid + 256 * it < COUNT) *reinterpret_cast<f32x4 *>(dst + (tid + 256 * it) * 4) = v[it];
+}
+// quad q of a transposed image [NT][8][64][4]: element i = W[k = 8 g + 4 (l >> 5) + i][c + n], n = 32 nt + (l & 31) < K (else 0);
+// lanes are consecutive n: every load covers whole 128-byte rows of W
+__device__ __forceinline__ f32x4 quad_t(const float *W, int64_t ld, int c, int K, int q) {
+    const int l = q & 63, g = (q >> 6) & 7, nt = q >> 9, n = nt * 32 + (l & 31);
+    const float *src = W + (int64_t)(8 * g + 4 * (l >> 5)) * ld + c + min(n, K - 1);
+    f32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = src[(int64_t)i * ld];
+    if (n >= K) v = f32x4{0.f, 0.f, 0.f, 0.f};
+    return v;
+}
+
 struct Args {
     const float *x0, *x1, *x2; int64_t ldx0, ldx1, ldx2; int K0, c0, c1, c2;      // pieces and their first columns in W1
     const float *W1; int64_t ldw1; const float *b1;                                // [64, Ktot]
@@ -64,32 +90,30 @@ __global__ __launch_bounds__(256, mlp_wpc(G0 + G1 + G2)) void mlp2_kernel(const 
     float *w1 = lds, *w2 = w1 + 2 * KG * 256, *w3 = w2 + (MODE != 1 ? 2 * 8 * 256 : 0), *bb = w3 + (MODE == 2 ? NT3 * 8 * 256 : 0);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     // ---- weight images: quad (tile nt, group g, lane l) = W[nt * 32 + (l & 31)][first column of g + 4 (l >> 5) .. + 3]
-    for (int e = tid; e < 2 * KG * 64; e += 256) {
+    stage_quads<2 * KG * 64>(w1, tid, [&](int e) {
         const int l = e & 63, g = (e >> 6) % KG, nt = (e >> 6) / KG;
         const int col = (g < G0 ? p.c0 + 8 * g : g < G0 + G1 ? p.c1 + 8 * (g - G0) : p.c2 + 8 * (g - G0 - G1)) + 4 * (l >> 5);
         const float *src = p.W1 + (int64_t)(nt * 32 + (l & 31)) * p.ldw1 + col;
         f32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = (!NARROW || g > 0 || 4 * (l >> 5) + i < p.K0) ? src[i] : 0.f;
-        *reinterpret_cast<f32x4 *>(w1 + e * 4) = v;
-    }
+        return v;
+    });
     if constexpr (MODE != 1) {
-        for (int e = tid; e < 2 * 8 * 64; e += 256) {
+        stage_quads<2 * 8 * 64>(w2, tid, [&](int e) {
             const int l = e & 63, g = (e >> 6) & 7, nt = e >> 9;
             const float *src = p.W2 + (int64_t)(nt * 32 + (l & 31)) * p.ldw2 + 8 * g + 4 * (l >> 5);
-            *reinterpret_cast<f32x4 *>(w2 + e * 4) = f32x4{src[0], src[1], src[2], src[3]};
-        }
+            return f32x4{src[0], src[1], src[2], src[3]};
+        });
     }
     if constexpr (MODE == 2) {               // the two heads stacked along the output features: [mean | logvar | zeros]
-        for (int e = tid; e < NT3 * 8 * 64; e += 256) {
-            const int l = e & 63, g = (e >> 6) & 7, nt = e >> 9, n = nt * 32 + (l & 31);
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < 2 * p.Z) {
-                const float *src = (n < p.Z ? p.Wm + (int64_t)n * p.ldwm : p.Wl + (int64_t)(n - p.Z) * p.ldwl) + 8 * g + 4 * (l >> 5);
-                v = f32x4{src[0], src[1], src[2], src[3]};
-            }
-            *reinterpret_cast<f32x4 *>(w3 + e * 4) = v;
-        }
+        stage_quads<NT3 * 8 * 64>(w3, tid, [&](int e) {
+            const int l = e & 63, g = (e >> 6) & 7, nt = e >> 9, n = nt * 32 + (l & 31), nc = min(n, 2 * p.Z - 1);
+            const float *src = (nc < p.Z ? p.Wm + (int64_t)nc * p.ldwm : p.Wl + (int64_t)(nc - p.Z) * p.ldwl) + 8 * g + 4 * (l >> 5);
+            f32x4 v = f32x4{src[0], src[1], src[2], src[3]};
+            if (n >= 2 * p.Z) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            return v;
+        });
     }
     if (tid < 64) {
         bb[tid] = p.b1 ? p.b1[tid] : 0.f;
@@ -382,24 +406,22 @@ __global__ __launch_bounds__(256, 3) void mlp2_bwd_kernel(const BArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
     // ---- transposed weight images: quad (tile nt, group g, lane l), element i = W[k = 8 g + 4 (l >> 5) + i][n = 32 nt + (l & 31)]
     if constexpr (G3 != 0) {
-        for (int e = tid; e < 2 * G3 * 256; e += 256) {
-            const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) % G3, nt = (e >> 8) / G3;
-            const int k = 8 * g + 4 * (l >> 5) + i, n = nt * 32 + (l & 31);
-            w3t[e] = k < p.Z ? p.Wm[(int64_t)k * p.ldwm + n] : (k < 2 * p.Z ? p.Wl[(int64_t)(k - p.Z) * p.ldwl + n] : 0.f);
-        }
+        stage_quads<2 * G3 * 64>(w3t, tid, [&](int q) {
+            const int l = q & 63, g = (q >> 6) % G3, nt = (q >> 6) / G3, n = nt * 32 + (l & 31);
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = 8 * g + 4 * (l >> 5) + i, kc = min(k, 2 * p.Z - 1);
+                const float *src = kc < p.Z ? p.Wm + (int64_t)kc * p.ldwm : p.Wl + (int64_t)(kc - p.Z) * p.ldwl;
+                const float w = src[n];
+                v[i] = k < 2 * p.Z ? w : 0.f;
+            }
+            return v;
+        });
     }
-    for (int e = tid; e < 2 * 8 * 256; e += 256) {
-        const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 7, nt = e >> 11;
-        w2t[e] = p.W2[(int64_t)(8 * g + 4 * (l >> 5) + i) * p.ldw2 + nt * 32 + (l & 31)];
-    }
-    for (int e = tid; e < NTA * 8 * 256; e += 256) {
-        const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 7, nt = e >> 11, n = nt * 32 + (l & 31);
-        wAt[e] = n < p.KA ? p.W1[(int64_t)(8 * g + 4 * (l >> 5) + i) * p.ldw1 + p.cA + n] : 0.f;
-    }
-    for (int e = tid; e < NTB * 8 * 256; e += 256) {
-        const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 7, nt = e >> 11, n = nt * 32 + (l & 31);
-        wBt[e] = n < p.KB ? p.W1[(int64_t)(8 * g + 4 * (l >> 5) + i) * p.ldw1 + p.cB + n] : 0.f;
-    }
+    stage_quads<2 * 8 * 64>(w2t, tid, [&](int q) { return quad_t(p.W2, p.ldw2, 0, 64, q); });
+    if constexpr (NTA != 0) stage_quads<(NTA ? NTA : 1) * 8 * 64>(wAt, tid, [&](int q) { return quad_t(p.W1, p.ldw1, p.cA, p.KA, q); });
+    if constexpr (NTB != 0) stage_quads<(NTB ? NTB : 1) * 8 * 64>(wBt, tid, [&](int q) { return quad_t(p.W1, p.ldw1, p.cB, p.KB, q); });
     __syncthreads();
 
     const int n_tiles = (p.M + 31) >> 5;
@@ -598,14 +620,8 @@ __global__ __launch_bounds__(256, 4) void linear_pieces_bwd_kernel(const PArgs p
     extern __shared__ float lds[];           // wAt [NTA][8][64][4] | wBt [NTB][8][64][4]
     float *wAt = lds, *wBt = wAt + NTA * 8 * 256;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 31, lh = lane >> 5;
-    for (int e = tid; e < NTA * 8 * 256; e += 256) {
-        const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 7, nt = e >> 11, n = nt * 32 + (l & 31);
-        wAt[e] = n < p.KA ? p.W[(int64_t)(8 * g + 4 * (l >> 5) + i) * p.ldw + p.cA + n] : 0.f;
-    }
-    for (int e = tid; e < NTB * 8 * 256; e += 256) {
-        const int i = e & 3, l = (e >> 2) & 63, g = (e >> 8) & 7, nt = e >> 11, n = nt * 32 + (l & 31);
-        wBt[e] = n < p.KB ? p.W[(int64_t)(8 * g + 4 * (l >> 5) + i) * p.ldw + p.cB + n] : 0.f;
-    }
+    stage_quads<NTA * 8 * 64>(wAt, tid, [&](int q) { return quad_t(p.W, p.ldw, p.cA, p.KA, q); });
+    if constexpr (NTB != 0) stage_quads<(NTB ? NTB : 1) * 8 * 64>(wBt, tid, [&](int q) { return quad_t(p.W, p.ldw, p.cB, p.KB, q); });
     __syncthreads();
     const int n_tiles = (p.M + 31) >> 5;
     const int stride = (int)gridDim.x * 4;

@@ -1432,13 +1432,16 @@ class SyncBnFn(torch.autograd.Function):
             ctx.shards = [(0, M)]
         _check(lib.dagnet_op_bn_merge(N, parts.shape[0], _p(parts), eps, momentum, _p(stat), _p(run_mean), _p(run_var), _p(total), st))
         _check(lib.dagnet_op_bn_apply(M, N, xp, ldx, _p(stat), _p(gamma), _p(beta), int(tanh_out), yp, ldy, st))
-        ctx.save_for_backward(x, gamma, stat, y, parts)
+        # (parts is NOT saved: it is a view of the step pool's stacked buffer, and the collective / copy_ that fills the next time
+        # step's view bumps the version counter they all share - autograd would then refuse this step's backward; nothing in the
+        # backward pass reads it)
+        ctx.save_for_backward(x, gamma, stat, y)
         ctx.tanh_out, ctx.virtual = tanh_out, BN_SYNC.mode == "virtual"
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma, stat, y, parts = ctx.saved_tensors
+        x, gamma, stat, y = ctx.saved_tensors
         lib, st = _lib(), _stream(x.device)
         M, N = x.shape
         dy = _rows(dy)

@@ -327,6 +327,24 @@ def test_sync_batchnorm_virtual_shards_match_the_whole_batch_golden(name):
     check_step(out, gold, meta["lr"], meta["clip"])
 
 
+@pytest.mark.parametrize("name", BN_CASES[:2])
+def test_sync_batchnorm_dist_mode_in_one_process_matches_the_golden(name):
+    """The "dist" form of synchronised BatchNorm (what `bench.py --sync-bn` and `loop.train(sync_batchnorm=True)` select) in a
+    single process: the gathered moments are this process's own, so the step must equal the whole-batch golden.  The gathered
+    buffer of every time step is a view of one stacked allocation that torch writes in place (collective / copy_): it must not be
+    among the tensors autograd saves (a step with several time steps failed with "modified by an inplace operation")."""
+    from dagnet_amd import _ops
+    meta, gold = cases.load_golden(name)
+    _, model, _ = cases.build_model(meta)
+    model = model.to(DEV)
+    prev = _ops.set_sync_batchnorm("dist")
+    try:
+        out = hip_train_step(meta, model)
+    finally:
+        _ops.set_sync_batchnorm(*prev)
+    check_step(out, gold, meta["lr"], meta["clip"])
+
+
 def test_per_shard_batchnorm_deviates_from_the_whole_batch_step():
     """What the default (per-rank BatchNorm statistics) costs under data parallelism: the same batch as two scene shards, each a
     forward / backward of its own with row_fraction weighting, gradients summed as the all-reduce would - against the reference's

@@ -690,7 +690,7 @@ def main():
         if n_chunks == 1 and not opt.no_reference_loop:
             # the reference's evaluation loop AS WRITTEN (models/dagnet/evaluate_bsk.py:113-114): K separate sample() calls
             # (untimed leg; one call first: the K = 1 plan is built once per batch layout).  The calls overlap on the device through
-            # two side streams (_capi._overlap_stream); reference_loop_serial_ms is the same loop on the caller's stream alone.
+            # three side streams (_capi._overlap_stream); reference_loop_serial_ms is the same loop on the caller's stream alone.
             def ref_loop(k0, count):
                 for k in range(k0, k0 + count):
                     if wl["kind"] == "dagnet":

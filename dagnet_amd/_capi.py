@@ -228,7 +228,7 @@ def sample(model: HipModel, plan: HipPlan, T: int, h0, x0=None, g0=None, eps=Non
 # --- small launches from a loop: K separate sample() calls (the reference's evaluation loop, models/dagnet/evaluate_bsk.py:113-114) ---
 # A launch of the register-resident kernel that does not fill the chip's wave slots a few times over leaves SIMDs idle while its
 # last waves finish, and the next call's launch waits behind it on the caller's stream although it depends on nothing the first one
-# writes.  Such launches go to one of two side streams instead: the side stream waits for an event recorded on the caller's stream
+# writes.  Such launches go to one of three side streams instead: the side stream waits for an event recorded on the caller's stream
 # when these INPUTS were first seen (same storage, same version counters: nothing torch knows of has written them since; the
 # tensors are kept referenced so that their addresses cannot be handed to other tensors), the caller's stream waits for the
 # launch's completion event, and consecutive calls overlap on the device like the tiles of one large launch.  DAGNET_NO_OVERLAP=1
@@ -262,8 +262,11 @@ def _overlap_stream(model: HipModel, plan: HipPlan, ins):
         st.update(key=key, refs=list(ins), ready=ready)
     streams = _side_streams.get(idx)
     if streams is None:
-        streams = _side_streams[idx] = [torch.cuda.Stream(device=idx), torch.cuda.Stream(device=idx)]
-    side = streams[st["n"] & 1]
+        # three side streams + the caller's = the four hardware queues a process has here (GPU_MAX_HW_QUEUES); launches of a few
+        # hundred tiles (512 scenes: 171) need more than two in flight to fill the chip
+        n_side = max(1, int(os.environ.get("DAGNET_OVERLAP_STREAMS", "3")))
+        streams = _side_streams[idx] = [torch.cuda.Stream(device=idx) for _ in range(n_side)]
+    side = streams[st["n"] % len(streams)]
     st["n"] += 1
     side.wait_event(st["ready"])
     return side

@@ -44,7 +44,7 @@ class RolloutModule(nn.Module, HipBacked):
         if seed is None and (eps is None or (q is None and g0 is not None)):
             seed = draw_seed()
         with torch.no_grad():
-            return _capi.sample(self.hip_model(dev), plan, int(T), h.detach().float(),
+            return _capi.sample(plan.model, plan, int(T), h.detach().float(),      # (plan.model: hip_plan has just checked the weights)
                                 None if x0 is None else x0.detach().float(), g0, eps, q, force_goals,
                                 seed or 0, return_goals)
 
@@ -62,7 +62,7 @@ class RolloutModule(nn.Module, HipBacked):
         if seed is None and eps is None:
             seed = draw_seed()
         with torch.no_grad():
-            losses, h = _capi.forward(self.hip_model(dev), plan, traj_rel.detach().float(),
+            losses, h = _capi.forward(plan.model, plan, traj_rel.detach().float(),
                                       None if traj is None else traj.detach().float(), goals, adj, adj_dense, eps, seed or 0)
         return losses.to(torch.float32), h
 

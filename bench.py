@@ -689,7 +689,7 @@ def main():
                                              "note": "the same step with DAGNET_NO_BF16X3 semantics (whole step incl. metrics, wall clock)"}
         if n_chunks == 1 and not opt.no_reference_loop:
             # the reference's evaluation loop AS WRITTEN (models/dagnet/evaluate_bsk.py:113-114): K separate sample() calls
-            # (untimed leg; one call first: the K = 1 plan is built once per batch layout).  The calls overlap on the device through
+            # (untimed leg, steady state: one untimed pass of the loop first, as a loader's second batch would see it).  The calls overlap on the device through
             # three side streams (_capi._overlap_stream); reference_loop_serial_ms is the same loop on the caller's stream alone.
             def ref_loop(k0, count):
                 for k in range(k0, k0 + count):
@@ -703,8 +703,8 @@ def main():
                 if serial:
                     os.environ["DAGNET_NO_OVERLAP"] = "1"
                 try:
-                    ref_loop(999, 1)
-                    torch.cuda.synchronize()
+                    ref_loop(999, K)        # one untimed pass: the K = 1 plan, and the allocator's blocks of the side streams (a
+                    torch.cuda.synchronize()  # hipMalloc inside the loop synchronises the device and hides the overlap)
                     t0 = time.perf_counter()
                     ref_loop(0, K)
                     torch.cuda.synchronize()

@@ -266,8 +266,8 @@ def _overlap_stream(model: HipModel, plan: HipPlan, ins):
         # hundred tiles (512 scenes: 171) need more than two in flight to fill the chip
         n_side = max(1, int(os.environ.get("DAGNET_OVERLAP_STREAMS", "3")))
         streams = _side_streams[idx] = [torch.cuda.Stream(device=idx) for _ in range(n_side)]
-    # two launches of half the chip's wave slots or more already fill it; a third stream only adds a queue to arbitrate (measured
-    # in bench.py's reference loop: 1 366 tiles per call 41.7 ms on two streams, 47 - 49 on three or four)
+    # two launches of half the chip's wave slots or more already fill it (and every further stream is one more allocator pool to
+    # warm: a hipMalloc inside a loop of calls synchronises the device)
     n_use = min(len(streams), 2) if 2 * n_tiles.value >= slots else len(streams)
     side = streams[st["n"] % n_use]
     st["n"] += 1

@@ -232,7 +232,8 @@ def sample(model: HipModel, plan: HipPlan, T: int, h0, x0=None, g0=None, eps=Non
 # when these INPUTS were first seen (same storage, same version counters: nothing torch knows of has written them since; the
 # tensors are kept referenced so that their addresses cannot be handed to other tensors), the caller's stream waits for the
 # launch's completion event, and consecutive calls overlap on the device like the tiles of one large launch.  DAGNET_NO_OVERLAP=1
-# switches it off.  Not used under graph capture, for launches of >= _OVERLAP_ROUNDS rounds, or for kernels that work in the
+# switches it off.  The bookkeeping is per model and not locked: callers that drive ONE model from several host threads should set
+# that variable.  Not used under graph capture, for launches of >= _OVERLAP_ROUNDS rounds, or for kernels that work in the
 # plan's buffers (wide head, generic kernel with global scratch).
 _OVERLAP_ROUNDS = 4
 _side_streams: Dict[int, list] = {}
